@@ -1,0 +1,147 @@
+"""Deterministic parameter generators + state_dict layouts for the hot path.
+
+There is no network in the build/bench environment, so the published checkpoints
+(api/models/download_models.sh:1, api/readme.md:60-74) cannot be fetched.  The bench and
+the parity tests use random-init weights of the reference architecture produced by a
+closed-form, platform-independent generator (splitmix64 over (tensor name, flat index)) --
+NOT torch.manual_seed, whose stream differs across versions/devices.
+
+Key layouts:
+  two-stream head : the 107-tensor state_dict of Two_Stream_RNN (api/mimamo_net.py:96-122)
+  ResNet50        : `<conv>.weight` [+ `.bias`] and `<conv>_bn.{weight,bias,running_mean,
+                    running_var}` with the Caffe-style layer names of the third-party
+                    resnet50_ferplus_dag model file (conv1_7x7_s2, conv2_1_1x1_reduce, ...).
+"""
+import numpy as np
+
+_MASK = np.uint64(0xFFFFFFFFFFFFFFFF)
+
+
+def _fnv1a(name):
+    h = 0xCBF29CE484222325
+    for ch in name.encode("utf-8"):
+        h ^= ch
+        h = (h * 0x100000001B3) & 0xFFFFFFFFFFFFFFFF
+    return h
+
+
+def _splitmix64(x):
+    with np.errstate(over="ignore"):
+        x = (x + np.uint64(0x9E3779B97F4A7C15)) & _MASK
+        z = x
+        z = ((z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)) & _MASK
+        z = ((z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)) & _MASK
+        return z ^ (z >> np.uint64(31))
+
+
+def det_uniform(name, shape, lo=-1.0, hi=1.0, seed=0):
+    """float32 array, value(i) = lo + (hi-lo) * u(i), u from splitmix64(fnv(name)^seed + i)."""
+    n = int(np.prod(shape)) if len(shape) else 1
+    base = np.uint64((_fnv1a(name) ^ (seed * 0x9E3779B97F4A7C15)) & 0xFFFFFFFFFFFFFFFF)
+    with np.errstate(over="ignore"):
+        idx = (np.arange(n, dtype=np.uint64) + base) & _MASK
+    bits = _splitmix64(idx) >> np.uint64(40)  # 24 random bits -> exact in float32
+    u = bits.astype(np.float64) / float(1 << 24)
+    return (lo + (hi - lo) * u).astype(np.float32).reshape(shape)
+
+
+def _he(name, shape, fan_in, seed, gain=1.0):
+    b = gain * float(np.sqrt(6.0 / fan_in))
+    return det_uniform(name, shape, -b, b, seed)
+
+
+def _bn(sd, prefix, c, seed, gamma=(0.8, 1.2)):
+    sd[prefix + ".weight"] = det_uniform(prefix + ".weight", (c,), gamma[0], gamma[1], seed)
+    sd[prefix + ".bias"] = det_uniform(prefix + ".bias", (c,), -0.1, 0.1, seed)
+    sd[prefix + ".running_mean"] = det_uniform(prefix + ".running_mean", (c,), -0.1, 0.1, seed)
+    sd[prefix + ".running_var"] = det_uniform(prefix + ".running_var", (c,), 0.8, 1.25, seed)
+
+
+def _lin(sd, prefix, cout, cin, seed, gain=1.0):
+    sd[prefix + ".weight"] = _he(prefix + ".weight", (cout, cin), cin, seed, gain)
+    sd[prefix + ".bias"] = det_uniform(prefix + ".bias", (cout,), -0.05, 0.05, seed)
+
+
+def _conv(sd, prefix, cout, cin, k, seed, bias=True, gain=1.0):
+    sd[prefix + ".weight"] = _he(prefix + ".weight", (cout, cin, k, k), cin * k * k, seed, gain)
+    if bias:
+        sd[prefix + ".bias"] = det_uniform(prefix + ".bias", (cout,), -0.05, 0.05, seed)
+
+
+TWO_STREAM_BN_KEYS = ("mlp.mlp.2", "mlp.mlp.6", "phasenet.conv_net.0.1", "phasenet.conv_net.0.4",
+                      "phasenet.conv_net.1.1", "phasenet.conv_net.1.4", "phasenet.conv_net.2.1",
+                      "phasenet.conv_net.2.4", "phasenet.fc.2", "phasenet.fc.6", "phasenet.classifier.1",
+                      "transform.2", "classifier.2")
+
+
+def make_two_stream_state_dict(seed=0, num_phase=12):
+    """Random-init state_dict with the exact key/shape layout of Two_Stream_RNN (107 tensors
+    incl. the 13 `num_batches_tracked` counters)."""
+    sd = {}
+    _lin(sd, "mlp.mlp.1", 256, 2048, seed)
+    _bn(sd, "mlp.mlp.2", 256, seed)
+    _lin(sd, "mlp.mlp.5", 256, 256, seed)
+    _bn(sd, "mlp.mlp.6", 256, seed)
+    nch = 2 * num_phase
+    chans = [(nch, 64), (nch + 64, 128), (128, 256)]
+    for i, (cin, cout) in enumerate(chans):
+        pre = "phasenet.conv_net.%d." % i
+        _conv(sd, pre + "0", cout, cin, 3, seed)
+        _bn(sd, pre + "1", cout, seed)
+        _conv(sd, pre + "3", cout, cout, 3, seed)
+        _bn(sd, pre + "4", cout, seed)
+    _lin(sd, "phasenet.fc.0", 256, 256, seed)
+    _bn(sd, "phasenet.fc.2", 256, seed)
+    _lin(sd, "phasenet.fc.4", 256, 256, seed)
+    _bn(sd, "phasenet.fc.6", 256, seed)
+    _lin(sd, "phasenet.classifier.0", 1, 256, seed)
+    _bn(sd, "phasenet.classifier.1", 1, seed)
+    _lin(sd, "transform.0", 256, 512, seed)
+    _bn(sd, "transform.2", 256, seed)
+    k = 1.0 / np.sqrt(128.0)
+    for l in range(2):
+        for sfx in ("", "_reverse"):
+            for nm, shape in (("weight_ih", (384, 256)), ("weight_hh", (384, 128)),
+                              ("bias_ih", (384,)), ("bias_hh", (384,))):
+                key = "rnns.%s_l%d%s" % (nm, l, sfx)
+                sd[key] = det_uniform(key, shape, -k, k, seed)
+    _lin(sd, "classifier.1", 2, 256, seed)
+    _bn(sd, "classifier.2", 2, seed)
+    for bn in TWO_STREAM_BN_KEYS:
+        sd[bn + ".num_batches_tracked"] = np.zeros((), dtype=np.int64)
+    return sd
+
+
+# (stage, blocks, mid, out, stride) -- Caffe-style ResNet-50
+RESNET50_STAGES = ((2, 3, 64, 256, 1), (3, 4, 128, 512, 2), (4, 6, 256, 1024, 2), (5, 3, 512, 2048, 2))
+# meta['mean'] of the third-party model (VGGFace2 statistics), std == [1,1,1]
+RESNET50_MEAN = (131.0912, 103.8827, 91.4953)
+
+
+def resnet50_layers(stride_on_first_1x1=True):
+    """[(name, cin, cout, k, stride, pad)] in forward order."""
+    layers = [("conv1_7x7_s2", 3, 64, 7, 2, 3)]
+    cin = 64
+    for stage, blocks, mid, cout, stride in RESNET50_STAGES:
+        for b in range(1, blocks + 1):
+            s = stride if b == 1 else 1
+            s1, s3 = (s, 1) if stride_on_first_1x1 else (1, s)
+            pre = "conv%d_%d_" % (stage, b)
+            if b == 1:
+                layers.append((pre + "1x1_proj", cin, cout, 1, s, 0))
+            layers.append((pre + "1x1_reduce", cin, mid, 1, s1, 0))
+            layers.append((pre + "3x3", mid, mid, 3, s3, 1))
+            layers.append((pre + "1x1_increase", mid, cout, 1, 1, 0))
+            cin = cout
+    return layers
+
+
+def make_resnet50_state_dict(seed=0):
+    """Random-init ResNet-50 trunk (He-scaled convs; BN gamma~1, beta~0, var~1; the last BN
+    of every bottleneck is damped so 16 residual adds keep activations O(1..10))."""
+    sd = {}
+    for name, cin, cout, k, _, _ in resnet50_layers():
+        _conv(sd, name, cout, cin, k, seed, bias=False)
+        damp = name.endswith("1x1_increase") or name.endswith("1x1_proj")
+        _bn(sd, name + "_bn", cout, seed, gamma=(0.35, 0.55) if damp else (0.8, 1.2))
+    return sd
