@@ -1,0 +1,150 @@
+/*
+ * mimamo_hip.h -- C ABI of libmimamo_hip.so: MI355X (gfx950) kernels for MIMAMO-Net's
+ * per-video inference hot path.
+ *
+ * The reference (wtomin/MIMAMO-Net) has no FFI layer: its operator surface is four Python
+ * classes that api/tester.py constructs and calls.  Each entry point below is the native
+ * replacement for one of those Python call sites (cited as file:line, relative to the
+ * reference repo); the Python classes in mimamo-net_amd/ with the reference's names bind
+ * them through ctypes, and INTEGRATION.md shows the stub a reference maintainer would add.
+ *
+ * Conventions
+ *   - plain C: device pointers are raw `float*` / `int32_t*` into HBM, sizes are int/int64_t,
+ *     `stream` is a hipStream_t passed as void* (NULL = the null stream).  No torch types.
+ *   - every function returns 0 (MM_OK) or a negative mm_status code; nothing throws.
+ *   - caller owns every buffer (inputs, outputs, workspace).  A handle owns only immutable
+ *     per-device constant tables (masks, DFT twiddles, BN-folded weights).
+ *   - calls only ENQUEUE work on `stream`; no hidden synchronisation (the reference's
+ *     device->host assert at api/phase_difference_extractor.py:105 is deliberately dropped).
+ *   - one handle per (process, device); calls on different handles are re-entrant.
+ *   - all arithmetic is fp32 (the reference pins torch.float32, SCFpyr_PyTorch.py:57-59).
+ */
+#ifndef MIMAMO_HIP_H
+#define MIMAMO_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MM_VERSION 100 /* 0.1.0 */
+
+typedef enum mm_status {
+    MM_OK = 0,
+    MM_ERR_INVALID_ARG = -1,   /* bad pointer / shape / unsupported configuration          */
+    MM_ERR_TOO_SMALL = -2,     /* "Cannot build N levels, image too small" (SCFpyr_PyTorch.py:90-91) */
+    MM_ERR_UNSUPPORTED = -3,   /* configuration the reference accepts but this build does not */
+    MM_ERR_HIP = -4,           /* a HIP runtime call failed; see mm_last_hip_error()        */
+    MM_ERR_NO_DEVICE = -5,     /* no gfx950 device visible                                  */
+    MM_ERR_WORKSPACE = -6      /* caller-provided workspace too small                       */
+} mm_status;
+
+int mm_version(void);
+const char* mm_status_string(int status);
+/* hipError_t of the last failing HIP call on this thread (0 if none). */
+int mm_last_hip_error(void);
+
+/* ---------------------------------------------------------------------------------------
+ * Steerable pyramid + phase difference
+ * replaces: Phase_Difference_Extractor.{__init__,build_pyramid,extract}
+ *           (api/phase_difference_extractor.py:7-37, 38-87, 93-134),
+ *           SCFpyr_PyTorch.build/_build_levels (api/steerable/SCFpyr_PyTorch.py:70-208),
+ *           symmetric_extension_batch/torch_unwrap/torch_diff/amplitude_based_gaussian_blur
+ *           (api/utils/phase_utils.py:5-40,78-129), Tester.phase_diff_output (api/tester.py:122-139)
+ * ------------------------------------------------------------------------------------- */
+typedef struct mm_pyramid mm_pyramid_t;
+
+/* size = side of the (un-mirrored) square input; the kernels mirror it to 2*size
+ * (symmetric_extension_batch).  Supported: size=48, height=4, nbands=2, scale_factor=2 --
+ * the one configuration api/tester.py:28-32 uses; anything else the reference would accept
+ * returns MM_ERR_UNSUPPORTED, height > floor(log2(2*size))-2 returns MM_ERR_TOO_SMALL. */
+int mm_pyramid_create(mm_pyramid_t** out, int size, int height, int nbands, int scale_factor);
+int mm_pyramid_destroy(mm_pyramid_t* h);
+
+/* Host-side constant builder exposed for testing (no GPU needed): writes the real-valued
+ * product of the reference's float64 masks for pyramid list item `level` (1 or 2), band
+ * `band`, on that level's (2*size / 2^(level-1))^2 grid, fftshift-ed layout exactly as
+ * SCFpyr_PyTorch builds them:  lo0 * [lomask_0 ...] * himask_level * anglemask_level_band.
+ * `out` must hold side*side doubles.  Also returns the crop bounds used going INTO that level
+ * (level 1: {0, 2*size}) in crop[0..1]. */
+int mm_pyramid_host_mask(int size, int height, int nbands, int level, int band, double* out, int* crop);
+
+/* frames: device f32 [n, size, size].  For every image and band writes the kept quadrant of the
+ * level-1 and level-2 complex band coefficients (interleaved re,im):
+ *   c1 + img*img_stride1 + band*band_stride1  ->  [size,   size,   2]
+ *   c2 + img*img_stride2 + band*band_stride2  ->  [size/2, size/2, 2]
+ * (strides in floats).  build_pyramid's return layout [B, nbands, P, W, H, 2] for im_batch
+ * [B,P,W,H] is obtained with n=B*P, image index (b*P+p): see mm_pyramid_build_batch. */
+int mm_pyramid_build(mm_pyramid_t* h, const float* frames, int64_t n,
+                     float* c1, int64_t img_stride1, int64_t band_stride1,
+                     float* c2, int64_t img_stride2, int64_t band_stride2, void* stream);
+
+/* Drop-in layout helper: im_batch [B,P,size,size] -> c1 [B,nbands,P,size,size,2],
+ * c2 [B,nbands,P,size/2,size/2,2] (phase_difference_extractor.py:76-86). */
+int mm_pyramid_build_batch(mm_pyramid_t* h, const float* im_batch, int64_t B, int64_t P,
+                           float* c1, float* c2, void* stream);
+
+/* Phase difference of J windows of P=13 coefficient planes (extract(), :93-134).
+ *   plane(j, i, band) = coeff + ids[j*P + i]*img_stride + band*band_stride   -> [W, W, 2]
+ * ids: device int32 [J*P].  W in {size, size/2}.
+ * out element (j, c = band*(P-1)+k, y, x):
+ *   out_nhwc == 0:  out[((j*C + c)*W + y)*W + x]                 (C = nbands*(P-1); tester.py:133-138)
+ *   out_nhwc == 1:  out[((j*W + y)*W + x)*out_cstride + out_coffset + c]   (feeds the head's NHWC convs)
+ */
+int mm_phase_extract(mm_pyramid_t* h, const float* coeff, const int32_t* ids,
+                     int64_t img_stride, int64_t band_stride, int64_t J, int P, int W,
+                     float* out, int out_nhwc, int out_cstride, int out_coffset, void* stream);
+
+/* Fused, de-duplicated driver for one batch of frames (the build's fast path): pyramid once
+ * per unique frame, then J windows gathered through window ids (snippet_sampler.py:144-152).
+ * frames [n,size,size]; ids int32 [J*13] in [0,n).  Outputs as in mm_phase_extract for W=size
+ * (out0) and W=size/2 (out1).  workspace: mm_phase_workspace_bytes(n) bytes of HBM. */
+int64_t mm_phase_workspace_bytes(mm_pyramid_t* h, int64_t n);
+int mm_phase_diff_frames(mm_pyramid_t* h, const float* frames, int64_t n, const int32_t* ids, int64_t J,
+                         float* out0, int out0_nhwc, int out0_cstride, int out0_coffset,
+                         float* out1, int out1_nhwc, int out1_cstride, int out1_coffset,
+                         void* workspace, int64_t workspace_bytes, void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Convolutional networks (fp32 MFMA implicit-GEMM engine)
+ * replaces: Resnet50_Extractor.get_vec (api/resnet50_extractor.py:74-83) and
+ *           Two_Stream_RNN.forward (api/mimamo_net.py:129-143)
+ * ------------------------------------------------------------------------------------- */
+typedef struct mm_resnet50 mm_resnet50_t;
+typedef struct mm_head mm_head_t;
+
+/* Weight blob: host f32 array, tensors concatenated in the order of mm_resnet50_blob_floats /
+ * documented in mimamo-net_amd/weights.py (per conv: weight OIHW, then BN gamma, beta,
+ * running_mean, running_var).  BN (eps) is folded into the conv on the host at create time.
+ * stride_on_first_1x1: 1 = Caffe-style (the third-party model file), 0 = torchvision-style. */
+int64_t mm_resnet50_blob_floats(void);
+int mm_resnet50_create(mm_resnet50_t** out, const float* host_blob, int64_t n_floats,
+                       int stride_on_first_1x1, int maxpool_ceil_mode, float bn_eps);
+int mm_resnet50_destroy(mm_resnet50_t* h);
+int64_t mm_resnet50_workspace_bytes(mm_resnet50_t* h, int64_t batch);
+/* images: device f32, [batch,3,224,224] (nchw=1, the reference's layout) or [batch,224,224,3];
+ * already normalised (255*x - mean, api/utils/model_utils.py:36-39).  out: [batch, 2048]
+ * = relu(pool5_7x7_s1) on the device (the reference copies it to a CPU tensor and squeeze()s
+ * it -- quirk Q8, not reproduced). */
+int mm_resnet50_forward(mm_resnet50_t* h, const float* images, int nchw, int64_t batch, float* out,
+                        void* workspace, int64_t workspace_bytes, void* stream);
+
+/* Two-stream head.  Blob: the Two_Stream_RNN state_dict float tensors in state_dict order
+ * (num_batches_tracked skipped); see weights.py `two_stream_blob`. */
+int64_t mm_head_blob_floats(void);
+int mm_head_create(mm_head_t** out, const float* host_blob, int64_t n_floats);
+int mm_head_destroy(mm_head_t* h);
+int64_t mm_head_workspace_bytes(mm_head_t* h, int64_t bs, int64_t T);
+/* phase_0 [bs,T,24,48,48] / phase_1 [bs,T,24,24,24] (phase_nhwc=0, reference layout) or
+ * NHWC [bs*T,48,48,24] / [bs*T,24,24,24] (phase_nhwc=1); rgb [bs,T,2048]; out [bs,T,2]
+ * (col 0 valence, col 1 arousal, tester.py:52).  The GRU runs over dim 0 (bs) with T as its
+ * batch, exactly like nn.GRU without batch_first (mimamo_net.py:119,139; quirk Q1). */
+int mm_head_forward(mm_head_t* h, const float* phase_0, const float* phase_1, int phase_nhwc,
+                    const float* rgb, int64_t bs, int64_t T, float* out,
+                    void* workspace, int64_t workspace_bytes, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MIMAMO_HIP_H */

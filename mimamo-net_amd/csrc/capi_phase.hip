@@ -1,0 +1,148 @@
+// extern "C" entry points: steerable pyramid + phase difference (see include/mimamo_hip.h).
+#include <cmath>
+#include <new>
+#include "mm_common.h"
+
+namespace mm {
+thread_local int g_last_hip_error = 0;
+
+int launch_pyramid(const mm_pyramid* h, const float* frames, int64_t n, int64_t group, float* c1, int64_t gs1,
+                   int64_t is1, int64_t bs1, float* c2, int64_t gs2, int64_t is2, int64_t bs2, hipStream_t stream);
+int pyramid_table_floats();
+int pack_pyramid_tables(const PyramidTables& t, std::vector<float>& packed);
+int launch_phase_window(const float* coeff, const int32_t* ids, int64_t img_stride, int64_t band_stride, int64_t J,
+                        int W, float* out, int out_nhwc, int out_cstride, int out_coffset, hipStream_t stream);
+
+static int check_config(int size, int height, int nbands, int scale_factor) {
+    if (size <= 0 || height < 1 || nbands < 1 || scale_factor < 1) return MM_ERR_INVALID_ARG;
+    // SCFpyr_PyTorch.py:90-91, evaluated on the mirrored side (phase_difference_extractor.py:44-47)
+    if (height > (int)std::floor(std::log2((double)(2 * size))) - 2) return MM_ERR_TOO_SMALL;
+    // nbands == 1 recurses forever in the reference (math_utils.py:79-84, quirk Q7)
+    if (size != 48 || height != 4 || nbands != 2 || scale_factor != 2) return MM_ERR_UNSUPPORTED;
+    return MM_OK;
+}
+}  // namespace mm
+
+extern "C" {
+
+int mm_version(void) { return MM_VERSION; }
+
+const char* mm_status_string(int s) {
+    switch (s) {
+        case MM_OK: return "ok";
+        case MM_ERR_INVALID_ARG: return "invalid argument";
+        case MM_ERR_TOO_SMALL: return "Cannot build the requested number of levels, image too small.";
+        case MM_ERR_UNSUPPORTED: return "configuration not supported by this build (supported: size=48, height=4, nbands=2, scale_factor=2)";
+        case MM_ERR_HIP: return "HIP runtime error";
+        case MM_ERR_NO_DEVICE: return "no gfx950 device";
+        case MM_ERR_WORKSPACE: return "workspace too small";
+        default: return "unknown status";
+    }
+}
+
+int mm_last_hip_error(void) { return mm::g_last_hip_error; }
+
+int mm_pyramid_host_mask(int size, int height, int nbands, int level, int band, double* out, int* crop) {
+    if (!out || !crop) return MM_ERR_INVALID_ARG;
+    if (size <= 0 || height < 3 || nbands < 2) return MM_ERR_INVALID_ARG;
+    if (height > (int)std::floor(std::log2((double)(2 * size))) - 2) return MM_ERR_TOO_SMALL;
+    mm::PyramidConfig c{size, height, nbands, 2};
+    std::vector<double> m;
+    int side = 0;
+    int rc = mm::host_level_mask(c, level, band, m, side, crop);
+    if (rc != MM_OK) return rc;
+    for (size_t i = 0; i < m.size(); ++i) out[i] = m[i];
+    return MM_OK;
+}
+
+int mm_pyramid_create(mm_pyramid_t** out, int size, int height, int nbands, int scale_factor) {
+    if (!out) return MM_ERR_INVALID_ARG;
+    *out = nullptr;
+    int rc = mm::check_config(size, height, nbands, scale_factor);
+    if (rc != MM_OK) return rc;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return MM_ERR_NO_DEVICE;
+    mm_pyramid* h = new (std::nothrow) mm_pyramid();
+    if (!h) return MM_ERR_INVALID_ARG;
+    h->cfg = mm::PyramidConfig{size, height, nbands, scale_factor};
+    h->d_tables = nullptr;
+    MM_HIP(hipGetDevice(&h->device));
+    mm::PyramidTables t;
+    rc = mm::build_pyramid_tables(h->cfg, t);
+    std::vector<float> packed;
+    if (rc == MM_OK) rc = mm::pack_pyramid_tables(t, packed);
+    if (rc != MM_OK) {
+        delete h;
+        return rc;
+    }
+    h->table_floats = (int64_t)packed.size();
+    hipError_t e = hipMalloc((void**)&h->d_tables, packed.size() * sizeof(float));
+    if (e == hipSuccess) e = hipMemcpy(h->d_tables, packed.data(), packed.size() * sizeof(float), hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        if (h->d_tables) (void)hipFree(h->d_tables);
+        delete h;
+        return mm::hip_fail(e);
+    }
+    *out = h;
+    return MM_OK;
+}
+
+int mm_pyramid_destroy(mm_pyramid_t* h) {
+    if (!h) return MM_OK;
+    if (h->d_tables) (void)hipFree(h->d_tables);
+    delete h;
+    return MM_OK;
+}
+
+int mm_pyramid_build(mm_pyramid_t* h, const float* frames, int64_t n, float* c1, int64_t is1, int64_t bs1, float* c2,
+                     int64_t is2, int64_t bs2, void* stream) {
+    if (!h || n < 0 || (n > 0 && (!frames || !c1 || !c2))) return MM_ERR_INVALID_ARG;
+    return mm::launch_pyramid(h, frames, n, n, c1, 0, is1, bs1, c2, 0, is2, bs2, (hipStream_t)stream);
+}
+
+// build_pyramid layout (phase_difference_extractor.py:82-85): image (b,p), band k -> plane [b][k][p],
+// i.e. groups of P images with group stride nb*P*plane, image stride plane, band stride P*plane.
+int mm_pyramid_build_batch(mm_pyramid_t* h, const float* im_batch, int64_t B, int64_t P, float* c1, float* c2,
+                           void* stream) {
+    if (!h || B < 0 || P <= 0 || (B > 0 && (!im_batch || !c1 || !c2))) return MM_ERR_INVALID_ARG;
+    const int64_t S = h->cfg.size, nb = h->cfg.nbands;
+    const int64_t plane1 = S * S * 2, plane2 = (S / 2) * (S / 2) * 2;
+    return mm::launch_pyramid(h, im_batch, B * P, P, c1, nb * P * plane1, plane1, P * plane1, c2, nb * P * plane2,
+                              plane2, P * plane2, (hipStream_t)stream);
+}
+
+int mm_phase_extract(mm_pyramid_t* h, const float* coeff, const int32_t* ids, int64_t img_stride, int64_t band_stride,
+                     int64_t J, int P, int W, float* out, int out_nhwc, int out_cstride, int out_coffset, void* stream) {
+    if (!h || J < 0 || (J > 0 && (!coeff || !ids || !out))) return MM_ERR_INVALID_ARG;
+    if (P != 13) return MM_ERR_UNSUPPORTED;  // num_phase = 12 (api/tester.py:28)
+    if (W != h->cfg.size && W != h->cfg.size / 2) return MM_ERR_UNSUPPORTED;
+    if (out_nhwc && (out_cstride < out_coffset + 2 * (P - 1) || out_coffset < 0)) return MM_ERR_INVALID_ARG;
+    return mm::launch_phase_window(coeff, ids, img_stride, band_stride, J, W, out, out_nhwc, out_cstride, out_coffset,
+                                   (hipStream_t)stream);
+}
+
+int64_t mm_phase_workspace_bytes(mm_pyramid_t* h, int64_t n) {
+    if (!h || n < 0) return MM_ERR_INVALID_ARG;
+    const int64_t S = h->cfg.size, nb = h->cfg.nbands;
+    return n * nb * (S * S * 2 + (S / 2) * (S / 2) * 2) * (int64_t)sizeof(float);
+}
+
+int mm_phase_diff_frames(mm_pyramid_t* h, const float* frames, int64_t n, const int32_t* ids, int64_t J, float* out0,
+                         int out0_nhwc, int out0_cstride, int out0_coffset, float* out1, int out1_nhwc,
+                         int out1_cstride, int out1_coffset, void* workspace, int64_t workspace_bytes, void* stream) {
+    if (!h || n <= 0 || J < 0 || !frames || !ids || !out0 || !out1 || !workspace) return MM_ERR_INVALID_ARG;
+    if (workspace_bytes < mm_phase_workspace_bytes(h, n)) return MM_ERR_WORKSPACE;
+    const int64_t S = h->cfg.size, nb = h->cfg.nbands;
+    const int64_t plane1 = S * S * 2, plane2 = (S / 2) * (S / 2) * 2;
+    float* c1 = (float*)workspace;           // [n][nb][S][S][2]
+    float* c2 = c1 + n * nb * plane1;        // [n][nb][S/2][S/2][2]
+    int rc = mm::launch_pyramid(h, frames, n, n, c1, 0, nb * plane1, plane1, c2, 0, nb * plane2, plane2,
+                                (hipStream_t)stream);
+    if (rc != MM_OK) return rc;
+    rc = mm_phase_extract(h, c1, ids, nb * plane1, plane1, J, 13, (int)S, out0, out0_nhwc, out0_cstride, out0_coffset, stream);
+    if (rc != MM_OK) return rc;
+    return mm_phase_extract(h, c2, ids, nb * plane2, plane2, J, 13, (int)S / 2, out1, out1_nhwc, out1_cstride,
+                            out1_coffset, stream);
+}
+
+}  // extern "C"

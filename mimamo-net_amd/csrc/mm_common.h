@@ -1,0 +1,55 @@
+// Shared declarations for libmimamo_hip.so (gfx950 only; no CUDA/compat paths).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <vector>
+#include "../../include/mimamo_hip.h"
+
+namespace mm {
+
+extern thread_local int g_last_hip_error;
+
+inline int hip_fail(hipError_t e) {
+    g_last_hip_error = (int)e;
+    return MM_ERR_HIP;
+}
+
+#define MM_HIP(call)                                  \
+    do {                                              \
+        hipError_t _e = (call);                       \
+        if (_e != hipSuccess) return mm::hip_fail(_e); \
+    } while (0)
+
+#define MM_LAUNCH_CHECK()                             \
+    do {                                              \
+        hipError_t _e = hipGetLastError();            \
+        if (_e != hipSuccess) return mm::hip_fail(_e); \
+    } while (0)
+
+// ---- host-side pyramid constants (mm_masks.cpp) -------------------------------------
+struct PyramidConfig {
+    int size;          // un-mirrored side (48)
+    int height, nbands, scale_factor;
+};
+
+// Real mask product on the level grid (fftshift-ed), float64; level in {1,2}.
+// side = 2*size >> (level-1).  crop = bounds applied going into that level.
+int host_level_mask(const PyramidConfig& c, int level, int band, std::vector<double>& out, int& side, int crop[2]);
+
+// Complex band tables in the kernels' half-plane layout (see pyramid.hip), fp32 (re,im interleaved).
+struct PyramidTables {
+    std::vector<float> dct;      // [48][48]  D[f][m] = 2 cos(pi f (2m+1)/96)
+    std::vector<float> ec, es;   // [48][48]  cos / sin (2 pi f q / 96)
+    std::vector<float> m1[2];    // level-1 band masks, complex: band0 [96][48][2], band1 [48][96][2]
+    std::vector<float> m2[2];    // level-2 band masks, complex: band0 [48][24][2], band1 [24][48][2]
+};
+int build_pyramid_tables(const PyramidConfig& c, PyramidTables& t);
+
+}  // namespace mm
+
+struct mm_pyramid {
+    mm::PyramidConfig cfg;
+    int device;
+    float* d_tables;   // one HBM allocation, sub-tables at fixed offsets (pyramid.hip)
+    int64_t table_floats;
+};

@@ -1,0 +1,155 @@
+"""Phase_Difference_Extractor on MI355X -- drop-in for api/phase_difference_extractor.py:6-134.
+
+Same constructor arguments, same method names, same tensor layouts; the arithmetic runs in
+libmimamo_hip.so (csrc/pyramid.hip, csrc/phase_window.hip) through the C ABI.  Tensors must live
+on a ROCm device ("cuda"); there is no CPU fallback.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+
+
+class Phase_Difference_Extractor(object):
+    def __init__(self, height=5, nbands=4, scale_factor=2, extract_level=1, visualize=False):
+        """Arguments as api/phase_difference_extractor.py:7-37.  This build implements the single
+        configuration the reference's Tester uses (api/tester.py:28-32): height=4, nbands=2,
+        scale_factor=2 on 48x48 inputs; other values raise NotImplementedError at the first call
+        (RuntimeError 'image too small' keeps the reference's meaning, SCFpyr_PyTorch.py:90-91)."""
+        if visualize:
+            raise NotImplementedError("visualize=True is a debug path of the reference (matplotlib); out of scope")
+        self.height = height
+        self.nbands = nbands
+        self.scale_factor = scale_factor
+        self.extract_level = extract_level
+        self.visualize = visualize
+        self._handle = None
+        self._size = None
+        self._ids_cache = {}
+
+    # -- native handle -------------------------------------------------------------------
+    def _get(self, size):
+        if self._handle is None or self._size != size:
+            self.close()
+            h = ctypes.c_void_p()
+            rc = _lib.lib().mm_pyramid_create(ctypes.byref(h), int(size), int(self.height), int(self.nbands),
+                                              int(self.scale_factor))
+            _lib.check(rc, "mm_pyramid_create")
+            self._handle, self._size = h, size
+        return self._handle
+
+    def close(self):
+        if self._handle is not None:
+            _lib.lib().mm_pyramid_destroy(self._handle)
+            self._handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @staticmethod
+    def _check_input(t, ndim, what):
+        if not isinstance(t, torch.Tensor):
+            raise ValueError("%s must be a torch.Tensor" % what)
+        if t.dim() != ndim:
+            raise ValueError("%s must have %d dimensions, got %d" % (what, ndim, t.dim()))
+        if not t.is_cuda:
+            raise RuntimeError("%s must be on a ROCm device (cuda); this build has no CPU path" % what)
+        assert t.dtype == torch.float32, "Image batch must be torch.float32"  # SCFpyr_PyTorch.py:82
+
+    # -- reference API -------------------------------------------------------------------
+    def build_pyramid(self, im_batch, symmetry=True):
+        """im_batch [B, P, W, H] -> coefficients [B, nbands, P, W_l, H_l, 2] (a list when extract_level is
+        a list) -- api/phase_difference_extractor.py:38-87."""
+        self._check_input(im_batch, 4, "im_batch")
+        if not symmetry:
+            raise NotImplementedError("symmetry=False is never used by the inference path")
+        B, P, W, H = im_batch.shape
+        assert W == H, "square frames only (SCFpyr_PyTorch.py:87 swaps height/width)"
+        h = self._get(W)
+        levels = [self.extract_level] if isinstance(self.extract_level, int) else list(self.extract_level)
+        for lv in levels:
+            if lv not in (1, 2):
+                raise NotImplementedError("extract_level %r: only pyramid list items 1 and 2 are produced" % (lv,))
+        x = im_batch.contiguous()
+        c1 = torch.empty((B, self.nbands, P, W, H, 2), dtype=torch.float32, device=x.device)
+        c2 = torch.empty((B, self.nbands, P, W // 2, H // 2, 2), dtype=torch.float32, device=x.device)
+        rc = _lib.lib().mm_pyramid_build_batch(h, _lib.ptr(x), B, P, _lib.ptr(c1), _lib.ptr(c2), _lib.current_stream())
+        _lib.check(rc, "mm_pyramid_build_batch")
+        out = [c1 if lv == 1 else c2 for lv in levels]
+        return out[0] if isinstance(self.extract_level, int) else out
+
+    def extract(self, coeff_batch):
+        """coeff [B, nbands, P, W, H, 2] -> phase differences [B, nbands, P-1, W, H]
+        (api/phase_difference_extractor.py:93-134)."""
+        if isinstance(coeff_batch, (list, tuple)):
+            raise ValueError("extract() takes the coefficients of ONE level")
+        self._check_input(coeff_batch, 6, "coeff_batch")
+        B, nb, P, W, H, two = coeff_batch.shape
+        assert two == 2 and W == H and nb == self.nbands
+        size = self._size if self._size is not None else (W if W >= 48 else 2 * W)
+        h = self._get(size)
+        c = coeff_batch.contiguous()
+        key = (B, P, nb, str(c.device))
+        ids = self._ids_cache.get(key)
+        if ids is None:
+            # plane (b, band, p) sits at ((b*nb + band)*P + p) * plane: ids = b*nb*P + p, band stride P*plane
+            ids = (torch.arange(B, device=c.device, dtype=torch.int32)[:, None] * (nb * P)
+                   + torch.arange(P, device=c.device, dtype=torch.int32)[None, :]).contiguous()
+            self._ids_cache = {key: ids}
+        out = torch.empty((B, nb, P - 1, W, H), dtype=torch.float32, device=c.device)
+        plane = W * H * 2
+        rc = _lib.lib().mm_phase_extract(h, _lib.ptr(c), _lib.ptr(ids), plane, P * plane, B, P, W, _lib.ptr(out),
+                                         0, 0, 0, _lib.current_stream())
+        _lib.check(rc, "mm_phase_extract")
+        return out
+
+    # -- fused fast path (not in the reference API) ---------------------------------------
+    def phase_diff_frames(self, frames, window_ids, nhwc=False, out1_cstride=None, out1_coffset=0):
+        """De-duplicated driver: unique frames [N, W, W] + window ids [J, 13] (int32, clamped frame indices,
+        api/sampler/snippet_sampler.py:144-152) -> (phase_0 [J,24,W,W], phase_1 [J,24,W/2,W/2]).
+
+        Builds each frame's pyramid once instead of once per window that contains it (13x less work than
+        Tester.phase_diff_output, identical results because the pyramid is per-frame -- quirk Q3).
+        nhwc=True writes channels-last tensors ([J,W,W,24], [J,W/2,W/2,out1_cstride] with the 24 channels
+        at out1_coffset) for the head's conv engine."""
+        self._check_input(frames, 3, "frames")
+        N, W, _ = frames.shape
+        J = window_ids.shape[0]
+        assert window_ids.dtype == torch.int32 and window_ids.is_cuda and tuple(window_ids.shape) == (J, 13)
+        h = self._get(W)
+        L = _lib.lib()
+        ws_bytes = L.mm_phase_workspace_bytes(h, N)
+        ws = torch.empty((ws_bytes // 4,), dtype=torch.float32, device=frames.device)
+        C = 2 * 12
+        if nhwc:
+            cs1 = C if out1_cstride is None else out1_cstride
+            p0 = torch.empty((J, W, W, C), dtype=torch.float32, device=frames.device)
+            p1 = torch.empty((J, W // 2, W // 2, cs1), dtype=torch.float32, device=frames.device)
+            args = (_lib.ptr(p0), 1, C, 0, _lib.ptr(p1), 1, cs1, out1_coffset)
+        else:
+            p0 = torch.empty((J, C, W, W), dtype=torch.float32, device=frames.device)
+            p1 = torch.empty((J, C, W // 2, W // 2), dtype=torch.float32, device=frames.device)
+            args = (_lib.ptr(p0), 0, 0, 0, _lib.ptr(p1), 0, 0, 0)
+        rc = L.mm_phase_diff_frames(h, _lib.ptr(frames.contiguous()), N, _lib.ptr(window_ids.contiguous()), J,
+                                    *args, _lib.ptr(ws), ws_bytes, _lib.current_stream())
+        _lib.check(rc, "mm_phase_diff_frames")
+        return p0, p1
+
+
+def phase_diff_output(phase_batch, steerable_pyramid):
+    """Tester.phase_diff_output (api/tester.py:122-139): [bs, T, 13, W, H] -> (phase_0 [bs,T,24,W,H],
+    phase_1 [bs,T,24,W/2,H/2])."""
+    sp = steerable_pyramid
+    bs, num_frames, num_phases, W, H = phase_batch.size()
+    coeff_batch = sp.build_pyramid(phase_batch.reshape(bs * num_frames, num_phases, W, H))
+    assert isinstance(coeff_batch, list)
+    outs = []
+    for c in coeff_batch:
+        d = sp.extract(c)
+        n, n_ch, n_ph, w, h = d.size()
+        outs.append(d.view(bs, num_frames, n_ch * n_ph, w, h))
+    return tuple(outs)

@@ -1,0 +1,146 @@
+"""GPU parity: steerable pyramid + phase difference (HIP, through the C ABI) vs the oracle and the
+golden fixtures frozen from the real reference."""
+import numpy as np
+import pytest
+import torch
+
+from mimamo_net_amd import synthetic
+
+pytestmark = pytest.mark.gpu
+
+# Tolerances (fp32 path; reference fp32-vs-fp64 noise floor measured in make_golden.py):
+COEFF_ATOL = 1e-6      # band coefficients (|c| ~ 1e-2..1e-1); reference fp32-vs-fp64 differs by 1.2e-7..2.5e-7
+PHASE_ATOL = 1e-3      # phase differences, away from +-pi branch cuts
+PHASE_P9999 = 3e-4     # 99.99th percentile of |err|
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "needs the MI355X"
+    return torch.device("cuda:0")
+
+
+@pytest.fixture(scope="module")
+def pde(pkg):
+    from mimamo_net_amd.phase_difference_extractor import Phase_Difference_Extractor
+    return Phase_Difference_Extractor(4, 2, 2, [1, 2], False)
+
+
+def _windows():
+    slow = synthetic.textured_gray(13, 48, seed=21)
+    ids = np.clip(np.arange(13) - 6, 0, None)
+    clamped = synthetic.textured_gray(7, 48, seed=22)[ids]
+    fast = synthetic.textured_gray(13 * 5, 48, seed=23)[::5]
+    return np.stack([slow, clamped, fast])[None]
+
+
+def _phase_err(a, b):
+    """max / p99.99 abs error ignoring isolated 2*pi branch flips (counted separately)."""
+    d = np.abs(a - b)
+    flips = d > 1.0
+    return d[~flips].max(), np.quantile(d[~flips], 0.9999), int(flips.sum())
+
+
+def test_pyramid_golden(pde, golden, dev):
+    g = golden("pyramid")
+    x = torch.from_numpy(synthetic.textured_gray(4, 48, seed=int(g["seed"])))[None].to(dev)
+    c1, c2 = pde.build_pyramid(x)
+    assert tuple(c1.shape) == (1, 2, 4, 48, 48, 2) and tuple(c2.shape) == (1, 2, 4, 24, 24, 2)
+    for got, f32, f64 in ((c1, g["l1_f32"], g["l1_f64"]), (c2, g["l2_f32"], g["l2_f64"])):
+        got = got.cpu().numpy()
+        assert np.abs(got - f32).max() < COEFF_ATOL, np.abs(got - f32).max()
+        assert np.abs(got - f64).max() < COEFF_ATOL, np.abs(got - f64).max()
+
+
+def test_pyramid_vs_oracle_random_batch(pde, oracle, dev):
+    x = np.stack([synthetic.textured_gray(13, 48, seed=100 + i) for i in range(5)])  # [5,13,48,48]
+    c1, c2 = pde.build_pyramid(torch.from_numpy(x).to(dev))
+    o1, o2 = oracle.build_pyramid(x.astype(np.float64), dtype=np.float64)
+    assert np.abs(c1.cpu().numpy() - o1).max() < COEFF_ATOL
+    assert np.abs(c2.cpu().numpy() - o2).max() < COEFF_ATOL
+    # white noise (no structure): still within tolerance
+    from mimamo_net_amd.weights import det_uniform
+    n = det_uniform("noise", (2, 3, 48, 48), 0.0, 1.0, 9)
+    c1, c2 = pde.build_pyramid(torch.from_numpy(n).to(dev))
+    o1, o2 = oracle.build_pyramid(n.astype(np.float64), dtype=np.float64)
+    assert np.abs(c1.cpu().numpy() - o1).max() < COEFF_ATOL
+    assert np.abs(c2.cpu().numpy() - o2).max() < COEFF_ATOL
+
+
+def test_extract_vs_oracle_same_coefficients(pde, oracle, dev):
+    """Isolates the window kernel: both sides start from the oracle's coefficients."""
+    w = _windows()[0]  # [3,13,48,48]
+    o1, o2 = oracle.build_pyramid(w)
+    for c in (o1, o2):
+        got = pde.extract(torch.from_numpy(c).to(dev)).cpu().numpy()
+        want = oracle.extract(c)
+        mx, p9999, flips = _phase_err(got, want)
+        assert got.shape == want.shape
+        assert mx < PHASE_ATOL and p9999 < PHASE_P9999 and flips <= 2, (mx, p9999, flips)
+
+
+def test_phase_diff_output_golden(pde, golden, dev):
+    from mimamo_net_amd.phase_difference_extractor import phase_diff_output
+    g = golden("extract")
+    p0, p1 = phase_diff_output(torch.from_numpy(_windows()).to(dev), pde)
+    assert tuple(p0.shape) == (1, 3, 24, 48, 48) and tuple(p1.shape) == (1, 3, 24, 24, 24)
+    for got, want in ((p0, g["phase_0"]), (p1, g["phase_1"])):
+        mx, p9999, flips = _phase_err(got.cpu().numpy()[0], want)
+        assert mx < PHASE_ATOL and p9999 < PHASE_P9999 and flips <= 2, (mx, p9999, flips)
+    # replicated frames (clamped window) -> exactly zero differences, like the reference
+    z = p0.cpu().numpy()[0, 1]
+    assert np.abs(z[0:6]).max() == 0.0 and np.abs(z[12:18]).max() == 0.0
+
+
+def test_dedup_fast_path_matches_drop_in(pde, oracle, dev):
+    from mimamo_net_amd.phase_difference_extractor import phase_diff_output
+    n = 40
+    frames = synthetic.textured_gray(n, 48, seed=55)
+    ids = oracle.window_ids(0, n, n).astype(np.int32)
+    f = torch.from_numpy(frames).to(dev)
+    i = torch.from_numpy(ids).to(dev)
+    a0, a1 = pde.phase_diff_frames(f, i)
+    b0, b1 = phase_diff_output(f[i.long()][None], pde)
+    assert torch.equal(a0, b0[0]) and torch.equal(a1, b1[0])  # same kernels, same per-frame pyramid: bit-identical
+    # channels-last variant used by the head's conv engine
+    n0, n1 = pde.phase_diff_frames(f, i, nhwc=True, out1_cstride=88, out1_coffset=64)
+    assert torch.equal(n0.permute(0, 3, 1, 2), a0)
+    assert torch.equal(n1[..., 64:88].permute(0, 3, 1, 2), a1)
+    # and against the oracle end to end
+    o0, o1 = oracle.phase_diff_from_frames(frames, ids)
+    for got, want in ((a0, o0), (a1, o1)):
+        mx, p9999, flips = _phase_err(got.cpu().numpy(), want)
+        assert mx < PHASE_ATOL and p9999 < PHASE_P9999 and flips <= 4, (mx, p9999, flips)
+
+
+def test_full_size_properties(pde, dev):
+    """BASELINE config 2 size (64-frame clips, several clips): size-independent properties."""
+    n = 64 * 4
+    frames = torch.from_numpy(synthetic.textured_gray(n, 48, seed=77)).to(dev)
+    ids = torch.clamp(torch.arange(n, device=dev)[:, None] + torch.arange(-6, 7, device=dev)[None, :], 0, n - 1).int()
+    p0, p1 = pde.phase_diff_frames(frames, ids.contiguous())
+    assert torch.isfinite(p0).all() and torch.isfinite(p1).all()
+    lim = 5 * np.pi + 1e-5
+    assert p0.abs().max() <= lim and p1.abs().max() <= lim
+    # spatial mean of every difference plane was removed (unless clamped): |mean| tiny
+    assert p0.mean(dim=(-1, -2)).abs().max() < 1e-4
+    # window invariance: shifting the clip by k frames shifts the interior outputs by k
+    q0, _ = pde.phase_diff_frames(frames[8:].contiguous(), ids[: n - 8].contiguous())
+    assert torch.equal(q0[6:-6], p0[14:-6])
+    # a constant-in-time clip has identically zero phase differences
+    still = frames[:1].repeat(32, 1, 1).contiguous()
+    s0, s1 = pde.phase_diff_frames(still, ids[:32].clamp(max=31).contiguous())
+    assert s0.abs().max() == 0 and s1.abs().max() == 0
+
+
+def test_error_behaviour(pkg, dev):
+    from mimamo_net_amd.phase_difference_extractor import Phase_Difference_Extractor
+    x = torch.zeros(1, 13, 48, 48, device=dev)
+    with pytest.raises(RuntimeError, match="image too small"):
+        Phase_Difference_Extractor(5, 2, 2, [1, 2]).build_pyramid(x)  # SCFpyr_PyTorch.py:90-91
+    with pytest.raises(NotImplementedError):
+        Phase_Difference_Extractor(4, 4, 2, [1, 2]).build_pyramid(x)
+    with pytest.raises(RuntimeError):
+        Phase_Difference_Extractor(4, 2, 2, [1, 2]).build_pyramid(x.cpu())
+    with pytest.raises(ValueError):
+        Phase_Difference_Extractor(4, 2, 2, [1, 2]).extract([x])
