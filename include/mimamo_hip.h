@@ -114,6 +114,20 @@ int mm_phase_diff_frames(mm_pyramid_t* h, const float* frames, int64_t n, const 
 typedef struct mm_resnet50 mm_resnet50_t;
 typedef struct mm_head mm_head_t;
 
+/* The conv engine itself (one launch): NHWC fp32 convolution / linear layer with fused epilogue
+ *   out = [post_scale *] relu?( conv(in, w) + bias [+ residual] ) [+ post_shift]
+ * in  [B,H,W,in_cstride]  channels [in_coff, in_coff+Cin) are read   (Cin, in_cstride, in_coff multiples of 4)
+ * w   [Cout][Kpad] packed weights, k = (r*kw + s)*Cin + c, Kpad = K rounded up to 16, zero filled
+ * out [B,Ho,Wo,out_cstride] channels [out_coff, out_coff+Cout) are written; residual [B,Ho,Wo,res_cstride].
+ * bias/residual/post_scale/post_shift may be NULL.  tile: 0 auto, 1 = 128x128, 2 = 128x64, 3 = 64x64.
+ * This is what torch.nn.functional.conv2d / linear + BatchNorm(eval) + ReLU lower to on this path
+ * (api/mimamo_net.py:14-26,68-78; the third-party ResNet50's conv/bn/relu triples). */
+int mm_conv2d_nhwc(const float* in, const float* w, const float* bias, const float* residual,
+                   const float* post_scale, const float* post_shift, float* out,
+                   int B, int H, int W, int Cin, int in_cstride, int in_coff,
+                   int Cout, int out_cstride, int out_coff, int res_cstride,
+                   int kh, int kw, int stride, int pad, int relu, int tile, void* stream);
+
 /* Weight blob: host f32 array, tensors concatenated in the order of mm_resnet50_blob_floats /
  * documented in mimamo-net_amd/weights.py (per conv: weight OIHW, then BN gamma, beta,
  * running_mean, running_var).  BN (eps) is folded into the conv on the host at create time.
@@ -123,7 +137,8 @@ int mm_resnet50_create(mm_resnet50_t** out, const float* host_blob, int64_t n_fl
                        int stride_on_first_1x1, int maxpool_ceil_mode, float bn_eps);
 int mm_resnet50_destroy(mm_resnet50_t* h);
 int64_t mm_resnet50_workspace_bytes(mm_resnet50_t* h, int64_t batch);
-/* images: device f32, [batch,3,224,224] (nchw=1, the reference's layout) or [batch,224,224,3];
+/* images: device f32, [batch,3,224,224] (nchw=1, the reference's layout) or channels-last padded to four
+ * channels [batch,224,224,4] (nchw=0; the 4th channel is ignored);
  * already normalised (255*x - mean, api/utils/model_utils.py:36-39).  out: [batch, 2048]
  * = relu(pool5_7x7_s1) on the device (the reference copies it to a CPU tensor and squeeze()s
  * it -- quirk Q8, not reproduced). */
@@ -137,7 +152,10 @@ int mm_head_create(mm_head_t** out, const float* host_blob, int64_t n_floats);
 int mm_head_destroy(mm_head_t* h);
 int64_t mm_head_workspace_bytes(mm_head_t* h, int64_t bs, int64_t T);
 /* phase_0 [bs,T,24,48,48] / phase_1 [bs,T,24,24,24] (phase_nhwc=0, reference layout) or
- * NHWC [bs*T,48,48,24] / [bs*T,24,24,24] (phase_nhwc=1); rgb [bs,T,2048]; out [bs,T,2]
+ * NHWC [bs*T,48,48,24] / [bs*T,24,24,24] (phase_nhwc=1), or NHWC with phase_1 already placed at channels
+ * 64..87 of a [bs*T,24,24,88] buffer that the call then completes in place (phase_nhwc=2, the fused
+ * pipeline: PhaseNet concatenates conv features and level-1 phase, mimamo_net.py:85);
+ * rgb [bs,T,2048]; out [bs,T,2]
  * (col 0 valence, col 1 arousal, tester.py:52).  The GRU runs over dim 0 (bs) with T as its
  * batch, exactly like nn.GRU without batch_first (mimamo_net.py:119,139; quirk Q1). */
 int mm_head_forward(mm_head_t* h, const float* phase_0, const float* phase_1, int phase_nhwc,

@@ -1,0 +1,39 @@
+// Internal interfaces of the conv / GEMM engine and the small elementwise kernels.
+#pragma once
+#include "mm_common.h"
+
+namespace mm {
+
+struct ConvParams {
+    const float* in;          // NHWC activations
+    const float* w;           // [Cout][Kpad], k = (r, s, c), zero padded
+    const float* bias;        // [Cout] or null
+    const float* res;         // residual (NHWC, same M) or null
+    const float* post_scale;  // affine applied AFTER ReLU (BN placed after ReLU) or null
+    const float* post_shift;
+    float* out;
+    int B, H, W, Cin, in_cstride, in_coff;
+    int Ho, Wo, Cout, out_cstride, out_coff;
+    int res_cstride, res_coff;
+    int kh, kw, stride, pad;
+    int K, Kpad;
+    int relu;
+    int force_tile;  // 0 auto, 1 = 128x128, 2 = 128x64, 3 = 64x64
+    int M, tiles_m, tiles_n;  // filled by conv_forward
+};
+
+int conv_forward(const ConvParams& p, hipStream_t stream);
+
+// NCHW [N,C,HW] -> NHWC [N,HW,cstride] at channel offset coff; channels [C, cpad) are zero-filled
+int nchw_to_nhwc(const float* in, float* out, int64_t N, int C, int HW, int cstride, int coff, int cpad, hipStream_t s);
+// MaxPool2d(k=3, s=2, pad=0, ceil_mode) on NHWC
+int maxpool3x3s2(const float* in, float* out, int64_t N, int H, int W, int C, int Ho, int Wo, hipStream_t s);
+// global average pool over HW (AvgPool2d(k=HW side)); optional ReLU afterwards
+int avgpool_hw(const float* in, float* out, int64_t N, int HW, int C, int out_cstride, int out_coff, int relu, hipStream_t s);
+// one GRU time step for a batch of Bt rows (PyTorch gate order r,z,n):
+//   gi [Bt, gi_stride] (+gi_off) = W_ih x + b_ih ; gh [Bt, 3H] = W_hh h + b_hh (or null with bhh => h == 0)
+//   h_out[b, out_stride*b + out_off + j] = (1-z)*n + z*h_prev
+int gru_gates(const float* gi, int gi_stride, int gi_off, const float* gh, const float* bhh, const float* h_prev,
+              int hp_stride, int hp_off, float* h_out, int out_stride, int out_off, int64_t Bt, int H, hipStream_t s);
+
+}  // namespace mm

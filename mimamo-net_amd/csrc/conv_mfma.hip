@@ -1,0 +1,202 @@
+// fp32 implicit-GEMM convolution on the gfx950 matrix cores (v_mfma_f32_32x32x2_f32).
+//
+// One engine serves every dense contraction of the hot path:
+//   * the 53 conv+BN(+ReLU)(+residual) layers of the ResNet50 trunk behind
+//     Resnet50_Extractor.get_vec (api/resnet50_extractor.py:74-83),
+//   * PhaseNet's six 3x3 convs and every nn.Linear of Two_Stream_RNN (api/mimamo_net.py:14-26,
+//     41-95,115-122), the GRU input/recurrent products (api/mimamo_net.py:119) -- a Linear is a
+//     1x1 conv on a 1x1 image.
+// fp32 in / fp32 accumulate: the MFMA is bit-for-bit an fmaf chain, so results differ from the
+// reference's fp32 convs only by summation order (the 1e-4 output tolerance of north_star rules
+// out bf16/fp16 operands).
+//
+// GEMM view:  out[m][n] = sum_k A[m][k] * Wt[n][k],  m = (b, ho, wo),  n = cout,  k = (r, s, c)
+//   activations NHWC (channel stride/offset allow channel-sliced reads and concat-writes),
+//   weights packed [Cout][Kpad] with k contiguous (Kpad = K rounded up to 16, zero filled).
+// Workgroup = 256 threads = 2x2 waves; block tile BM x BN x 16; each wave owns (BM/2)x(BN/2) as
+// 32x32 MFMA sub-tiles.  Both operand tiles are staged [row][16+4] in LDS: the +4 pad makes the
+// ds_read_b128 fragment reads and the global->LDS float4 writes bank-conflict free.  Inside a
+// 16-deep chunk lanes 0-31 take k = 0..7 and lanes 32-63 take k = 8..15 (any k order is a valid
+// contraction order), so one b128 read feeds four MFMAs.  Global loads for chunk i+1 are issued
+// before the MFMAs of chunk i (register prefetch, double-buffered LDS, one barrier per chunk).
+// Epilogue (fused): + bias (BN folded on the host) [+ residual] [ReLU] [* post_scale + post_shift]
+// (BN placed after ReLU, mimamo_net.py:54-62,115-117), stored as 128-byte channel rows.
+#include "mm_common.h"
+#include "conv.h"
+
+namespace mm {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int CBK = 16;   // k-chunk
+constexpr int CLD = 20;   // LDS row stride (floats)
+
+template <int BM, int BN>
+__global__ void __launch_bounds__(256)
+conv_mfma_kernel(const ConvParams p) {
+    constexpr int WM = BM / 2, WN = BN / 2;
+    constexpr int TM = WM / 32, TN = WN / 32;
+    constexpr int AIT = BM / 64, BIT = BN / 64;
+    __shared__ __attribute__((aligned(16))) float lds[2 * (BM + BN) * CLD];
+    float* As = lds;                      // [2][BM][CLD]
+    float* Bs = lds + 2 * BM * CLD;       // [2][BN][CLD]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+
+    // XCD-aware tile order: workgroup b runs on XCD b % 8; give each XCD a contiguous run of logical
+    // tiles, n-tiles of one m-tile adjacent, so the activation rows they share stay in that XCD's L2.
+    const int nblk = gridDim.x;
+    int logical;
+    {
+        const int b = blockIdx.x, xcd = b & 7, idx = b >> 3;
+        const int q = nblk >> 3, r = nblk & 7;
+        logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int tile_m = logical / p.tiles_n, tile_n = logical - tile_m * p.tiles_n;
+    const int m_base = tile_m * BM, n_base = tile_n * BN;
+
+    // ---- per-thread gather state: rows (tid>>2) + 64*it, k-quad (tid&3)
+    const int kq = tid & 3, lrow = tid >> 2;
+    int a_hi0[AIT], a_wi0[AIT];
+    int64_t a_base[AIT];
+    bool a_ok[AIT];
+#pragma unroll
+    for (int it = 0; it < AIT; ++it) {
+        const int m = m_base + lrow + it * 64;
+        a_ok[it] = m < p.M;
+        const int mm_ = a_ok[it] ? m : 0;
+        const int hw = p.Ho * p.Wo;
+        const int b = mm_ / hw, rem = mm_ - b * hw;
+        const int ho = rem / p.Wo, wo = rem - ho * p.Wo;
+        a_hi0[it] = ho * p.stride - p.pad;
+        a_wi0[it] = wo * p.stride - p.pad;
+        a_base[it] = (int64_t)b * p.H * p.W * p.in_cstride + p.in_coff;
+    }
+    const float* b_ptr[BIT];
+    bool b_ok[BIT];
+#pragma unroll
+    for (int it = 0; it < BIT; ++it) {
+        const int n = n_base + lrow + it * 64;
+        b_ok[it] = n < p.Cout;
+        b_ptr[it] = p.w + (int64_t)(b_ok[it] ? n : 0) * p.Kpad + kq * 4;
+    }
+
+    float4 ra[AIT], rb[BIT];
+    auto gload = [&](int kc) {
+        const int k0 = kc * CBK + kq * 4;
+        const int rs = k0 / p.Cin, c = k0 - rs * p.Cin;
+        const int r = rs / p.kw, s = rs - r * p.kw;
+        const bool kok = k0 < p.K;
+#pragma unroll
+        for (int it = 0; it < AIT; ++it) {
+            const int hi = a_hi0[it] + r, wi = a_wi0[it] + s;
+            const bool ok = kok && a_ok[it] && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
+            const float* src = p.in + a_base[it] + ((int64_t)hi * p.W + wi) * p.in_cstride + c;
+            ra[it] = ok ? *reinterpret_cast<const float4*>(src) : float4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int it = 0; it < BIT; ++it)
+            rb[it] = b_ok[it] ? *reinterpret_cast<const float4*>(b_ptr[it] + kc * CBK) : float4{0.f, 0.f, 0.f, 0.f};
+    };
+    auto lstore = [&](int buf) {
+#pragma unroll
+        for (int it = 0; it < AIT; ++it)
+            *reinterpret_cast<float4*>(As + (buf * BM + lrow + it * 64) * CLD + kq * 4) = ra[it];
+#pragma unroll
+        for (int it = 0; it < BIT; ++it)
+            *reinterpret_cast<float4*>(Bs + (buf * BN + lrow + it * 64) * CLD + kq * 4) = rb[it];
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    const int lr = lane & 31, lh = lane >> 5;
+    const int nk = p.Kpad / CBK;
+    gload(0);
+    lstore(0);
+    __syncthreads();
+    for (int kc = 0; kc < nk; ++kc) {
+        const int buf = kc & 1;
+        if (kc + 1 < nk) gload(kc + 1);
+        float af[TM][8], bf[TN][8];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const float4* s = reinterpret_cast<const float4*>(As + (buf * BM + wm * WM + i * 32 + lr) * CLD + lh * 8);
+            const float4 v0 = s[0], v1 = s[1];
+            af[i][0] = v0.x; af[i][1] = v0.y; af[i][2] = v0.z; af[i][3] = v0.w;
+            af[i][4] = v1.x; af[i][5] = v1.y; af[i][6] = v1.z; af[i][7] = v1.w;
+        }
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const float4* s = reinterpret_cast<const float4*>(Bs + (buf * BN + wn * WN + j * 32 + lr) * CLD + lh * 8);
+            const float4 v0 = s[0], v1 = s[1];
+            bf[j][0] = v0.x; bf[j][1] = v0.y; bf[j][2] = v0.z; bf[j][3] = v0.w;
+            bf[j][4] = v1.x; bf[j][5] = v1.y; bf[j][6] = v1.z; bf[j][7] = v1.w;
+        }
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk)
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][kk], bf[j][kk], acc[i][j], 0, 0, 0);
+        if (kc + 1 < nk) lstore(buf ^ 1);
+        __syncthreads();
+    }
+
+    // ---- fused epilogue.  C layout: col = lane & 31, row = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int n = n_base + wn * WN + j * 32 + lr;
+        const bool nok = n < p.Cout;
+        const float bias = (nok && p.bias) ? p.bias[n] : 0.f;
+        const float ps = (nok && p.post_scale) ? p.post_scale[n] : 1.f;
+        const float pt = (nok && p.post_shift) ? p.post_shift[n] : 0.f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int m = m_base + wm * WM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+                if (nok && m < p.M) {
+                    float v = acc[i][j][e] + bias;
+                    if (p.res) v += p.res[(int64_t)m * p.res_cstride + p.res_coff + n];
+                    if (p.relu) v = fmaxf(v, 0.f);
+                    if (p.post_scale) v = v * ps + pt;
+                    p.out[(int64_t)m * p.out_cstride + p.out_coff + n] = v;
+                }
+            }
+        }
+    }
+}
+
+template <int BM, int BN>
+static int launch_cfg(ConvParams p, hipStream_t stream) {
+    p.tiles_m = (p.M + BM - 1) / BM;
+    p.tiles_n = (p.Cout + BN - 1) / BN;
+    const int64_t blocks = (int64_t)p.tiles_m * p.tiles_n;
+    if (blocks <= 0 || blocks > 0x7fffffff) return MM_ERR_INVALID_ARG;
+    hipLaunchKernelGGL((conv_mfma_kernel<BM, BN>), dim3((unsigned)blocks), dim3(256), 0, stream, p);
+    MM_LAUNCH_CHECK();
+    return MM_OK;
+}
+
+int conv_forward(const ConvParams& p0, hipStream_t stream) {
+    ConvParams p = p0;
+    if (p.Cin % 4 || p.in_cstride % 4 || p.in_coff % 4 || p.Kpad % CBK || p.K > p.Kpad) return MM_ERR_INVALID_ARG;
+    p.M = p.B * p.Ho * p.Wo;
+    if (p.M <= 0) return MM_OK;
+    // tile choice: the largest tile that still gives every CU (256) a couple of workgroups
+    const int64_t t128 = (int64_t)((p.M + 127) / 128) * ((p.Cout + 127) / 128);
+    if (p.force_tile == 1 || (p.force_tile == 0 && p.Cout > 64 && t128 >= 512)) return launch_cfg<128, 128>(p, stream);
+    const int64_t t12864 = (int64_t)((p.M + 127) / 128) * ((p.Cout + 63) / 64);
+    if (p.force_tile == 2 || (p.force_tile == 0 && t12864 >= 512)) return launch_cfg<128, 64>(p, stream);
+    return launch_cfg<64, 64>(p, stream);
+}
+
+}  // namespace mm

@@ -1,0 +1,127 @@
+// Memory-bound helpers around the conv engine (layout change, pooling, GRU gates).  All are
+// coalesced along the channel dimension of NHWC tensors (float4 where the shape allows).
+#include "conv.h"
+
+namespace mm {
+
+// ---- NCHW -> NHWC through an LDS tile (reads coalesced along HW, writes along C) ------------------
+__global__ void __launch_bounds__(256)
+nchw_to_nhwc_kernel(const float* __restrict__ in, float* __restrict__ out, int C, int HW, int cstride, int coff, int cpad) {
+    __shared__ float tile[32][33];
+    const int64_t n = blockIdx.z;
+    const int hw0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+    for (int r = ty; r < 32; r += 8) {
+        const int c = c0 + r, hw = hw0 + tx;
+        tile[r][tx] = (c < C && hw < HW) ? in[(n * C + c) * HW + hw] : 0.f;
+    }
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) {
+        const int hw = hw0 + r, c = c0 + tx;
+        if (hw < HW && c < cpad) out[(n * HW + hw) * cstride + coff + c] = tile[tx][r];
+    }
+}
+
+int nchw_to_nhwc(const float* in, float* out, int64_t N, int C, int HW, int cstride, int coff, int cpad, hipStream_t s) {
+    if (N <= 0) return MM_OK;
+    if (cpad < C) cpad = C;
+    dim3 grid((HW + 31) / 32, (cpad + 31) / 32, (unsigned)N);
+    hipLaunchKernelGGL(nchw_to_nhwc_kernel, grid, dim3(256), 0, s, in, out, C, HW, cstride, coff, cpad);
+    MM_LAUNCH_CHECK();
+    return MM_OK;
+}
+
+// ---- MaxPool 3x3 stride 2 pad 0, ceil_mode windows clipped at the border ---------------------------
+__global__ void __launch_bounds__(256)
+maxpool_kernel(const float* __restrict__ in, float* __restrict__ out, int64_t total4, int H, int W, int C4, int Ho, int Wo) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total4) return;
+    const int c4 = (int)(i % C4);
+    int64_t t = i / C4;
+    const int wo = (int)(t % Wo); t /= Wo;
+    const int ho = (int)(t % Ho);
+    const int64_t n = t / Ho;
+    const float4* src = reinterpret_cast<const float4*>(in);
+    float4 m = {-3.4e38f, -3.4e38f, -3.4e38f, -3.4e38f};
+    for (int r = 0; r < 3; ++r) {
+        const int hi = ho * 2 + r;
+        if (hi >= H) break;
+        for (int q = 0; q < 3; ++q) {
+            const int wi = wo * 2 + q;
+            if (wi >= W) break;
+            const float4 v = src[((n * H + hi) * W + wi) * C4 + c4];
+            m.x = fmaxf(m.x, v.x); m.y = fmaxf(m.y, v.y); m.z = fmaxf(m.z, v.z); m.w = fmaxf(m.w, v.w);
+        }
+    }
+    reinterpret_cast<float4*>(out)[i] = m;
+}
+
+int maxpool3x3s2(const float* in, float* out, int64_t N, int H, int W, int C, int Ho, int Wo, hipStream_t s) {
+    if (C % 4) return MM_ERR_INVALID_ARG;
+    const int64_t total4 = N * Ho * Wo * (C / 4);
+    if (total4 <= 0) return MM_OK;
+    hipLaunchKernelGGL(maxpool_kernel, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, s, in, out, total4, H, W, C / 4, Ho, Wo);
+    MM_LAUNCH_CHECK();
+    return MM_OK;
+}
+
+// ---- global average pool ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+avgpool_kernel(const float* __restrict__ in, float* __restrict__ out, int64_t total, int HW, int C, int out_cstride, int out_coff, int relu) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int c = (int)(i % C);
+    const int64_t n = i / C;
+    float s = 0.f;
+    for (int p = 0; p < HW; ++p) s += in[(n * HW + p) * C + c];
+    s *= 1.0f / HW;
+    if (relu) s = fmaxf(s, 0.f);
+    out[n * out_cstride + out_coff + c] = s;
+}
+
+int avgpool_hw(const float* in, float* out, int64_t N, int HW, int C, int out_cstride, int out_coff, int relu, hipStream_t s) {
+    const int64_t total = N * C;
+    if (total <= 0) return MM_OK;
+    hipLaunchKernelGGL(avgpool_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, in, out, total, HW, C, out_cstride, out_coff, relu);
+    MM_LAUNCH_CHECK();
+    return MM_OK;
+}
+
+// ---- GRU cell (nn.GRU gate order r, z, n; mimamo_net.py:119) ----------------------------------------
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
+
+__global__ void __launch_bounds__(256)
+gru_gates_kernel(const float* __restrict__ gi, int gi_stride, int gi_off, const float* __restrict__ gh,
+                 const float* __restrict__ bhh, const float* __restrict__ h_prev, int hp_stride, int hp_off,
+                 float* __restrict__ h_out, int out_stride, int out_off, int64_t total, int H) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int j = (int)(i % H);
+    const int64_t b = i / H;
+    const float* g = gi + b * gi_stride + gi_off;
+    float hr, hz, hn, hp;
+    if (gh) {
+        const float* q = gh + b * 3 * H;
+        hr = q[j]; hz = q[H + j]; hn = q[2 * H + j];
+        hp = h_prev[b * hp_stride + hp_off + j];
+    } else {  // first step: h == 0  ->  W_hh h + b_hh = b_hh
+        hr = bhh[j]; hz = bhh[H + j]; hn = bhh[2 * H + j];
+        hp = 0.f;
+    }
+    const float r = sigmoidf_(g[j] + hr);
+    const float z = sigmoidf_(g[H + j] + hz);
+    const float n = tanhf(g[2 * H + j] + r * hn);
+    h_out[b * out_stride + out_off + j] = (1.f - z) * n + z * hp;
+}
+
+int gru_gates(const float* gi, int gi_stride, int gi_off, const float* gh, const float* bhh, const float* h_prev,
+              int hp_stride, int hp_off, float* h_out, int out_stride, int out_off, int64_t Bt, int H, hipStream_t s) {
+    const int64_t total = Bt * H;
+    if (total <= 0) return MM_OK;
+    hipLaunchKernelGGL(gru_gates_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, gi, gi_stride, gi_off, gh, bhh,
+                       h_prev, hp_stride, hp_off, h_out, out_stride, out_off, total, H);
+    MM_LAUNCH_CHECK();
+    return MM_OK;
+}
+
+}  // namespace mm

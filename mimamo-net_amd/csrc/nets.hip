@@ -1,0 +1,499 @@
+// Network executors on top of the conv engine: ResNet50 trunk to pool5 and the two-stream head.
+//
+//   mm_resnet50_*  <- Resnet50_Extractor.get_vec (api/resnet50_extractor.py:74-83).  The layer graph is the
+//                     third-party `resnet50_ferplus_dag` model the reference loads by name
+//                     (api/utils/model_utils.py:65-79; Caffe-style ResNet-50: stride on the first 1x1 of a
+//                     stage, ceil-mode 3x3/2 max pool, 7x7 average pool `pool5_7x7_s1`).
+//   mm_head_*      <- Two_Stream_RNN.forward (api/mimamo_net.py:129-143): MLP (:14-26), PhaseNet (:41-95),
+//                     transform (:115-118), 2-layer bidirectional GRU over dim 0 (:119,139), classifier (:120-122).
+// Eval-mode BatchNorm is folded into the preceding conv/linear on the host (float64) when it directly follows it;
+// BatchNorm placed after a ReLU (PhaseNet.fc, transform) runs as the conv engine's post-ReLU affine.
+#include <cmath>
+#include <cstring>
+#include <new>
+#include "conv.h"
+
+namespace mm {
+
+struct Layer {
+    float *w = nullptr, *bias = nullptr, *ps = nullptr, *pt = nullptr;
+    int cin = 0, cin_p = 0, cout = 0, k = 1, stride = 1, pad = 0, K = 0, Kpad = 0, relu = 0;
+};
+
+struct DeviceArena {
+    std::vector<void*> ptrs;
+    int upload(const std::vector<float>& h, float** out) {
+        *out = nullptr;
+        if (h.empty()) return MM_OK;
+        void* d = nullptr;
+        MM_HIP(hipMalloc(&d, h.size() * sizeof(float)));
+        ptrs.push_back(d);
+        MM_HIP(hipMemcpy(d, h.data(), h.size() * sizeof(float), hipMemcpyHostToDevice));
+        *out = (float*)d;
+        return MM_OK;
+    }
+    void release() {
+        for (void* p : ptrs) (void)hipFree(p);
+        ptrs.clear();
+    }
+};
+
+struct BN {
+    const float *gamma, *beta, *mean, *var;
+};
+
+// Build one conv/linear layer from host tensors.  w: [cout][cin][k][k] (OIHW), bias may be null.
+// fold: BN directly after the conv (scale into the weights).  post: BN after the ReLU.
+static int make_layer(DeviceArena& A, Layer& L, const float* w, const float* bias, int cout, int cin, int k, int stride,
+                      int pad, int relu, const BN* fold, const BN* post, float eps) {
+    L.cin = cin;
+    L.cin_p = (cin + 3) / 4 * 4;
+    L.cout = cout;
+    L.k = k;
+    L.stride = stride;
+    L.pad = pad;
+    L.relu = relu;
+    L.K = k * k * L.cin_p;
+    L.Kpad = (L.K + 15) / 16 * 16;
+    std::vector<float> hw((size_t)cout * L.Kpad, 0.f), hb(cout, 0.f);
+    for (int o = 0; o < cout; ++o) {
+        double sc = 1.0, sh = 0.0;
+        if (fold) {
+            sc = (double)fold->gamma[o] / std::sqrt((double)fold->var[o] + (double)eps);
+            sh = (double)fold->beta[o] - (double)fold->mean[o] * sc;
+        }
+        for (int c = 0; c < cin; ++c)
+            for (int r = 0; r < k; ++r)
+                for (int s = 0; s < k; ++s)
+                    hw[(size_t)o * L.Kpad + (size_t)(r * k + s) * L.cin_p + c] =
+                        (float)((double)w[(((size_t)o * cin + c) * k + r) * k + s] * sc);
+        hb[o] = (float)((bias ? (double)bias[o] : 0.0) * sc + sh);
+    }
+    int rc = A.upload(hw, &L.w);
+    if (rc == MM_OK) rc = A.upload(hb, &L.bias);
+    if (rc == MM_OK && post) {
+        std::vector<float> ps(cout), pt(cout);
+        for (int o = 0; o < cout; ++o) {
+            const double sc = (double)post->gamma[o] / std::sqrt((double)post->var[o] + (double)eps);
+            ps[o] = (float)sc;
+            pt[o] = (float)((double)post->beta[o] - (double)post->mean[o] * sc);
+        }
+        rc = A.upload(ps, &L.ps);
+        if (rc == MM_OK) rc = A.upload(pt, &L.pt);
+    }
+    return rc;
+}
+
+static int run_layer(const Layer& L, const float* in, int B, int H, int W, int in_cstride, int in_coff, float* out,
+                     int out_cstride, int out_coff, const float* res, int res_cstride, hipStream_t s, int* Ho_ = nullptr,
+                     int* Wo_ = nullptr) {
+    ConvParams p;
+    std::memset(&p, 0, sizeof(p));
+    p.in = in; p.w = L.w; p.bias = L.bias; p.res = res; p.post_scale = L.ps; p.post_shift = L.pt; p.out = out;
+    p.B = B; p.H = H; p.W = W; p.Cin = L.cin_p; p.in_cstride = in_cstride; p.in_coff = in_coff;
+    p.Ho = (H + 2 * L.pad - L.k) / L.stride + 1;
+    p.Wo = (W + 2 * L.pad - L.k) / L.stride + 1;
+    p.Cout = L.cout; p.out_cstride = out_cstride; p.out_coff = out_coff;
+    p.res_cstride = res_cstride; p.res_coff = 0;
+    p.kh = L.k; p.kw = L.k; p.stride = L.stride; p.pad = L.pad;
+    p.K = L.K; p.Kpad = L.Kpad; p.relu = L.relu;
+    if (Ho_) *Ho_ = p.Ho;
+    if (Wo_) *Wo_ = p.Wo;
+    return conv_forward(p, s);
+}
+
+struct Bump {
+    char* base;
+    int64_t off = 0, cap;
+    Bump(void* b, int64_t c) : base((char*)b), cap(c) {}
+    float* take(int64_t floats) {
+        const int64_t bytes = (floats * 4 + 255) / 256 * 256;
+        float* p = (float*)(base + off);
+        off += bytes;
+        return p;
+    }
+    static int64_t size_of(int64_t floats) { return (floats * 4 + 255) / 256 * 256; }
+};
+
+// ======================================= ResNet50 =====================================================
+static const int kStages[4][4] = {{3, 64, 256, 1}, {4, 128, 512, 2}, {6, 256, 1024, 2}, {3, 512, 2048, 2}};
+
+struct Bottleneck {
+    Layer proj, reduce, conv3, increase;
+    bool has_proj;
+};
+
+}  // namespace mm
+
+struct mm_resnet50 {
+    mm::DeviceArena arena;
+    mm::Layer stem;
+    std::vector<mm::Bottleneck> blocks;
+    int ceil_mode;
+};
+
+struct mm_head {
+    mm::DeviceArena arena;
+    mm::Layer mlp1, mlp2, conv[6], fc1, fc2, transform, gru_ih[2], gru_hh[2][2], classifier;
+    float* bhh[2][2];
+};
+
+namespace mm {
+
+static int64_t resnet_blob_floats() {
+    int64_t n = 64 * 3 * 49 + 4 * 64;
+    int cin = 64;
+    for (auto& st : kStages)
+        for (int b = 0; b < st[0]; ++b) {
+            const int mid = st[1], cout = st[2];
+            if (b == 0) n += (int64_t)cout * cin + 4 * cout;
+            n += (int64_t)mid * cin + 4 * mid;
+            n += (int64_t)mid * mid * 9 + 4 * mid;
+            n += (int64_t)cout * mid + 4 * cout;
+            cin = cout;
+        }
+    return n;
+}
+
+// per-frame workspace floats (see mm_resnet50_forward)
+static const int64_t kRsIn4 = 224 * 224 * 4, kRsBig = 112 * 112 * 64, kRsMid = 56 * 56 * 128;
+
+static int64_t head_blob_floats() {
+    int64_t n = 0;
+    auto lin = [&](int o, int i) { n += (int64_t)o * i + o; };
+    auto bn = [&](int c) { n += 4 * c; };
+    lin(256, 2048); bn(256); lin(256, 256); bn(256);
+    const int ch[3][2] = {{24, 64}, {88, 128}, {128, 256}};
+    for (auto& c : ch) { n += (int64_t)c[1] * c[0] * 9 + c[1]; bn(c[1]); n += (int64_t)c[1] * c[1] * 9 + c[1]; bn(c[1]); }
+    lin(256, 256); bn(256); lin(256, 256); bn(256); lin(1, 256); bn(1);
+    lin(256, 512); bn(256);
+    n += 4 * (384 * 256 + 384 * 128 + 384 + 384);
+    lin(2, 256); bn(2);
+    return n;
+}
+
+}  // namespace mm
+
+extern "C" {
+
+int mm_conv2d_nhwc(const float* in, const float* w, const float* bias, const float* residual, const float* post_scale,
+                   const float* post_shift, float* out, int B, int H, int W, int Cin, int in_cstride, int in_coff,
+                   int Cout, int out_cstride, int out_coff, int res_cstride, int kh, int kw, int stride, int pad,
+                   int relu, int tile, void* stream) {
+    using namespace mm;
+    if (!in || !w || !out || B < 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || kh <= 0 || kw <= 0 || stride <= 0 ||
+        pad < 0 || tile < 0 || tile > 3)
+        return MM_ERR_INVALID_ARG;
+    if ((post_scale == nullptr) != (post_shift == nullptr)) return MM_ERR_INVALID_ARG;
+    ConvParams p;
+    std::memset(&p, 0, sizeof(p));
+    p.in = in; p.w = w; p.bias = bias; p.res = residual; p.post_scale = post_scale; p.post_shift = post_shift; p.out = out;
+    p.B = B; p.H = H; p.W = W; p.Cin = Cin; p.in_cstride = in_cstride; p.in_coff = in_coff;
+    p.Ho = (H + 2 * pad - kh) / stride + 1;
+    p.Wo = (W + 2 * pad - kw) / stride + 1;
+    if (p.Ho <= 0 || p.Wo <= 0 || (int64_t)B * p.Ho * p.Wo > 0x7fffffff) return MM_ERR_INVALID_ARG;
+    p.Cout = Cout; p.out_cstride = out_cstride; p.out_coff = out_coff; p.res_cstride = res_cstride;
+    p.kh = kh; p.kw = kw; p.stride = stride; p.pad = pad;
+    p.K = kh * kw * Cin; p.Kpad = (p.K + 15) / 16 * 16; p.relu = relu; p.force_tile = tile;
+    return conv_forward(p, (hipStream_t)stream);
+}
+
+int64_t mm_resnet50_blob_floats(void) { return mm::resnet_blob_floats(); }
+
+int mm_resnet50_create(mm_resnet50_t** out, const float* blob, int64_t n_floats, int stride_on_first_1x1,
+                       int maxpool_ceil_mode, float bn_eps) {
+    using namespace mm;
+    if (!out) return MM_ERR_INVALID_ARG;
+    *out = nullptr;
+    if (!blob || n_floats != resnet_blob_floats()) return MM_ERR_INVALID_ARG;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return MM_ERR_NO_DEVICE;
+    mm_resnet50* h = new (std::nothrow) mm_resnet50();
+    if (!h) return MM_ERR_INVALID_ARG;
+    h->ceil_mode = maxpool_ceil_mode;
+    const float* p = blob;
+    int rc = MM_OK;
+    auto conv_bn = [&](Layer& L, int cout, int cin, int k, int stride, int pad, int relu) {
+        const float* w = p;
+        p += (int64_t)cout * cin * k * k;
+        BN bn{p, p + cout, p + 2 * cout, p + 3 * cout};
+        p += 4 * cout;
+        if (rc == MM_OK) rc = make_layer(h->arena, L, w, nullptr, cout, cin, k, stride, pad, relu, &bn, nullptr, bn_eps);
+    };
+    conv_bn(h->stem, 64, 3, 7, 2, 3, 1);
+    int cin = 64;
+    for (auto& st : kStages)
+        for (int b = 0; b < st[0]; ++b) {
+            const int mid = st[1], cout = st[2], s = b == 0 ? st[3] : 1;
+            const int s1 = stride_on_first_1x1 ? s : 1, s3 = stride_on_first_1x1 ? 1 : s;
+            h->blocks.emplace_back();
+            Bottleneck& B = h->blocks.back();
+            B.has_proj = b == 0;
+            if (b == 0) conv_bn(B.proj, cout, cin, 1, s, 0, 0);
+            conv_bn(B.reduce, mid, cin, 1, s1, 0, 1);
+            conv_bn(B.conv3, mid, mid, 3, s3, 1, 1);
+            conv_bn(B.increase, cout, mid, 1, 1, 0, 1);  // ReLU applies after the residual add (fused epilogue)
+            cin = cout;
+        }
+    if (rc != MM_OK) {
+        h->arena.release();
+        delete h;
+        return rc;
+    }
+    *out = h;
+    return MM_OK;
+}
+
+int mm_resnet50_destroy(mm_resnet50_t* h) {
+    if (!h) return MM_OK;
+    h->arena.release();
+    delete h;
+    return MM_OK;
+}
+
+int64_t mm_resnet50_workspace_bytes(mm_resnet50_t* h, int64_t batch) {
+    using namespace mm;
+    if (!h || batch < 0) return MM_ERR_INVALID_ARG;
+    return Bump::size_of(batch * kRsIn4) + 3 * Bump::size_of(batch * kRsBig) + 2 * Bump::size_of(batch * kRsMid);
+}
+
+int mm_resnet50_forward(mm_resnet50_t* h, const float* images, int nchw, int64_t batch, float* out, void* workspace,
+                        int64_t workspace_bytes, void* stream_) {
+    using namespace mm;
+    if (!h || batch < 0 || (batch > 0 && (!images || !out || !workspace))) return MM_ERR_INVALID_ARG;
+    if (batch == 0) return MM_OK;
+    if (batch > 40000) return MM_ERR_INVALID_ARG;  // M = batch*112*112 must fit int32
+    if (workspace_bytes < mm_resnet50_workspace_bytes(h, batch)) return MM_ERR_WORKSPACE;
+    hipStream_t s = (hipStream_t)stream_;
+    const int B = (int)batch;
+    Bump ws(workspace, workspace_bytes);
+    float* in4 = ws.take(batch * kRsIn4);
+    float* big[3] = {ws.take(batch * kRsBig), ws.take(batch * kRsBig), ws.take(batch * kRsBig)};
+    float* y1 = ws.take(batch * kRsMid);
+    float* y2 = ws.take(batch * kRsMid);
+    int rc;
+    const float* x0 = images;
+    if (nchw) {
+        rc = nchw_to_nhwc(images, in4, batch, 3, 224 * 224, 4, 0, 4, s);
+        if (rc != MM_OK) return rc;
+        x0 = in4;
+    }
+    int H = 224, W = 224, Ho, Wo;
+    rc = run_layer(h->stem, x0, B, H, W, 4, 0, big[0], 64, 0, nullptr, 0, s, &Ho, &Wo);
+    if (rc != MM_OK) return rc;
+    H = Ho; W = Wo;
+    // MaxPool2d(3, 2, pad 0, ceil_mode)
+    if (h->ceil_mode) {
+        Ho = (H - 3 + 1) / 2 + 1; Wo = (W - 3 + 1) / 2 + 1;
+        if ((Ho - 1) * 2 >= H) --Ho;
+        if ((Wo - 1) * 2 >= W) --Wo;
+    } else {
+        Ho = (H - 3) / 2 + 1; Wo = (W - 3) / 2 + 1;
+    }
+    rc = maxpool3x3s2(big[0], big[1], batch, H, W, 64, Ho, Wo, s);
+    if (rc != MM_OK) return rc;
+    H = Ho; W = Wo;
+    int xi = 1;  // index of the buffer holding the block input
+    int C = 64;
+    for (const Bottleneck& Bk : h->blocks) {
+        float* x = big[xi];
+        float* sc = big[(xi + 1) % 3];
+        float* o = big[(xi + 2) % 3];
+        int H1, W1, H2, W2, H3, W3;
+        const float* resid = x;
+        if (Bk.has_proj) {
+            rc = run_layer(Bk.proj, x, B, H, W, C, 0, sc, Bk.proj.cout, 0, nullptr, 0, s);
+            if (rc != MM_OK) return rc;
+            resid = sc;
+        }
+        rc = run_layer(Bk.reduce, x, B, H, W, C, 0, y1, Bk.reduce.cout, 0, nullptr, 0, s, &H1, &W1);
+        if (rc != MM_OK) return rc;
+        rc = run_layer(Bk.conv3, y1, B, H1, W1, Bk.reduce.cout, 0, y2, Bk.conv3.cout, 0, nullptr, 0, s, &H2, &W2);
+        if (rc != MM_OK) return rc;
+        rc = run_layer(Bk.increase, y2, B, H2, W2, Bk.conv3.cout, 0, o, Bk.increase.cout, 0, resid, Bk.increase.cout, s, &H3, &W3);
+        if (rc != MM_OK) return rc;
+        H = H3; W = W3; C = Bk.increase.cout;
+        xi = (xi + 2) % 3;
+    }
+    // pool5_7x7_s1 + relu(squeeze)  (resnet50_extractor.py:83)
+    if (H != 7 || W != 7) return MM_ERR_UNSUPPORTED;
+    return avgpool_hw(big[xi], out, batch, H * W, C, C, 0, 1, s);
+}
+
+// ============================================ head =====================================================
+int64_t mm_head_blob_floats(void) { return mm::head_blob_floats(); }
+
+int mm_head_create(mm_head_t** out, const float* blob, int64_t n_floats) {
+    using namespace mm;
+    if (!out) return MM_ERR_INVALID_ARG;
+    *out = nullptr;
+    if (!blob || n_floats != head_blob_floats()) return MM_ERR_INVALID_ARG;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return MM_ERR_NO_DEVICE;
+    mm_head* h = new (std::nothrow) mm_head();
+    if (!h) return MM_ERR_INVALID_ARG;
+    const float eps = 1e-5f;
+    const float* p = blob;
+    int rc = MM_OK;
+    auto take = [&](int64_t n) { const float* q = p; p += n; return q; };
+    auto take_bn = [&](int c) { BN b{p, p + c, p + 2 * c, p + 3 * c}; p += 4 * c; return b; };
+    // Linear -> BN -> ReLU  (MLP, mimamo_net.py:14-20)
+    auto lin_bn_relu = [&](Layer& L, int o, int i) {
+        const float* w = take((int64_t)o * i); const float* b = take(o); BN bn = take_bn(o);
+        if (rc == MM_OK) rc = make_layer(h->arena, L, w, b, o, i, 1, 1, 0, 1, &bn, nullptr, eps);
+    };
+    // Conv3x3(+bias) -> BN -> ReLU  (PhaseNet._make_conv_layer, :68-78)
+    auto conv_bn_relu = [&](Layer& L, int o, int i, int stride) {
+        const float* w = take((int64_t)o * i * 9); const float* b = take(o); BN bn = take_bn(o);
+        if (rc == MM_OK) rc = make_layer(h->arena, L, w, b, o, i, 3, stride, 1, 1, &bn, nullptr, eps);
+    };
+    // Linear -> ReLU -> BN  (PhaseNet.fc :54-62, transform :115-117)
+    auto lin_relu_bn = [&](Layer& L, int o, int i) {
+        const float* w = take((int64_t)o * i); const float* b = take(o); BN bn = take_bn(o);
+        if (rc == MM_OK) rc = make_layer(h->arena, L, w, b, o, i, 1, 1, 0, 1, nullptr, &bn, eps);
+    };
+    lin_bn_relu(h->mlp1, 256, 2048);
+    lin_bn_relu(h->mlp2, 256, 256);
+    const int ch[3][2] = {{24, 64}, {88, 128}, {128, 256}};
+    for (int i = 0; i < 3; ++i) {
+        conv_bn_relu(h->conv[2 * i], ch[i][1], ch[i][0], 1);
+        conv_bn_relu(h->conv[2 * i + 1], ch[i][1], ch[i][1], 2);
+    }
+    lin_relu_bn(h->fc1, 256, 256);
+    lin_relu_bn(h->fc2, 256, 256);
+    take(256 + 1); take_bn(1);  // phasenet.classifier: unused with feature=True (:91-92)
+    lin_relu_bn(h->transform, 256, 512);
+    // GRU: state_dict order per (layer, direction): weight_ih, weight_hh, bias_ih, bias_hh
+    for (int l = 0; l < 2 && rc == MM_OK; ++l) {
+        std::vector<float> wih(768 * 256), bih(768);
+        for (int d = 0; d < 2; ++d) {
+            const float* w_ih = take(384 * 256); const float* w_hh = take(384 * 128);
+            const float* b_ih = take(384); const float* b_hh = take(384);
+            std::memcpy(wih.data() + (size_t)d * 384 * 256, w_ih, sizeof(float) * 384 * 256);
+            std::memcpy(bih.data() + (size_t)d * 384, b_ih, sizeof(float) * 384);
+            if (rc == MM_OK) rc = make_layer(h->arena, h->gru_hh[l][d], w_hh, b_hh, 384, 128, 1, 1, 0, 0, nullptr, nullptr, eps);
+            std::vector<float> bh(b_hh, b_hh + 384);
+            if (rc == MM_OK) rc = h->arena.upload(bh, &h->bhh[l][d]);
+        }
+        if (rc == MM_OK) rc = make_layer(h->arena, h->gru_ih[l], wih.data(), bih.data(), 768, 256, 1, 1, 0, 0, nullptr, nullptr, eps);
+    }
+    {   // classifier: Dropout, Linear(256,2), BatchNorm1d(2)  (:120-122)
+        const float* w = take(2 * 256); const float* b = take(2); BN bn = take_bn(2);
+        if (rc == MM_OK) rc = make_layer(h->arena, h->classifier, w, b, 2, 256, 1, 1, 0, 0, &bn, nullptr, eps);
+    }
+    if (rc == MM_OK && p - blob != n_floats) rc = MM_ERR_INVALID_ARG;
+    if (rc != MM_OK) {
+        h->arena.release();
+        delete h;
+        return rc;
+    }
+    *out = h;
+    return MM_OK;
+}
+
+int mm_head_destroy(mm_head_t* h) {
+    if (!h) return MM_OK;
+    h->arena.release();
+    delete h;
+    return MM_OK;
+}
+
+namespace {
+struct HeadWs {
+    int64_t p0n, a0, cat, a1, a2, a3, a4, pool, fc1, m1, feat, f, gi, gh, l0, l1;
+};
+HeadWs head_sizes(int64_t N, int64_t T) {
+    HeadWs s;
+    s.p0n = N * 48 * 48 * 24; s.a0 = N * 48 * 48 * 64; s.cat = N * 24 * 24 * 88; s.a1 = N * 24 * 24 * 128;
+    s.a2 = N * 12 * 12 * 128; s.a3 = N * 12 * 12 * 256; s.a4 = N * 6 * 6 * 256; s.pool = N * 256; s.fc1 = N * 256;
+    s.m1 = N * 256; s.feat = N * 512; s.f = N * 256; s.gi = N * 768; s.gh = T * 384; s.l0 = N * 256; s.l1 = N * 256;
+    return s;
+}
+}  // namespace
+
+int64_t mm_head_workspace_bytes(mm_head_t* h, int64_t bs, int64_t T) {
+    using mm::Bump;
+    if (!h || bs < 0 || T < 0) return MM_ERR_INVALID_ARG;
+    const HeadWs s = head_sizes(bs * T, T);
+    const int64_t all[] = {s.p0n, s.a0, s.cat, s.a1, s.a2, s.a3, s.a4, s.pool, s.fc1, s.m1, s.feat, s.f, s.gi, s.gh, s.l0, s.l1};
+    int64_t tot = 0;
+    for (int64_t v : all) tot += Bump::size_of(v);
+    return tot;
+}
+
+int mm_head_forward(mm_head_t* h, const float* phase_0, const float* phase_1, int phase_nhwc, const float* rgb,
+                    int64_t bs, int64_t T, float* out, void* workspace, int64_t workspace_bytes, void* stream_) {
+    using namespace mm;
+    if (!h || bs < 0 || T < 0) return MM_ERR_INVALID_ARG;
+    const int64_t N64 = bs * T;
+    if (N64 == 0) return MM_OK;
+    if (!phase_0 || !phase_1 || !rgb || !out || !workspace || N64 > 400000) return MM_ERR_INVALID_ARG;
+    if (workspace_bytes < mm_head_workspace_bytes(h, bs, T)) return MM_ERR_WORKSPACE;
+    hipStream_t s = (hipStream_t)stream_;
+    const int N = (int)N64;
+    const HeadWs z = head_sizes(N64, T);
+    Bump ws(workspace, workspace_bytes);
+    float* p0n = ws.take(z.p0n); float* a0 = ws.take(z.a0); float* cat = ws.take(z.cat); float* a1 = ws.take(z.a1);
+    float* a2 = ws.take(z.a2); float* a3 = ws.take(z.a3); float* a4 = ws.take(z.a4); float* pool = ws.take(z.pool);
+    float* fc1 = ws.take(z.fc1); float* m1 = ws.take(z.m1); float* feat = ws.take(z.feat); float* f = ws.take(z.f);
+    float* gi = ws.take(z.gi); float* gh = ws.take(z.gh); float* l0 = ws.take(z.l0); float* l1 = ws.take(z.l1);
+    int rc;
+#define MM_TRY(x) do { rc = (x); if (rc != MM_OK) return rc; } while (0)
+    // ---- temporal stream: PhaseNet (mimamo_net.py:79-92)
+    const float* x0 = phase_0;
+    if (!phase_nhwc) {
+        MM_TRY(nchw_to_nhwc(phase_0, p0n, N64, 24, 48 * 48, 24, 0, 24, s));
+        MM_TRY(nchw_to_nhwc(phase_1, cat, N64, 24, 24 * 24, 88, 64, 24, s));  // torch.cat([conv1, level1], dim=1) (:85)
+        x0 = p0n;
+    } else if (phase_nhwc == 2) {
+        // phase_1 IS the concat buffer [N,24,24,88] with the level-1 channels already at 64..87 (written
+        // there by mm_phase_diff_frames); conv[1] fills channels 0..63 in place.
+        cat = const_cast<float*>(phase_1);
+    } else {
+        // phase_1 given as [N,24,24,24] NHWC: place it behind the 64 conv channels
+        MM_HIP(hipMemcpy2DAsync(cat + 64, 88 * sizeof(float), phase_1, 24 * sizeof(float), 24 * sizeof(float),
+                                (size_t)N64 * 24 * 24, hipMemcpyDeviceToDevice, s));
+    }
+    MM_TRY(run_layer(h->conv[0], x0, N, 48, 48, 24, 0, a0, 64, 0, nullptr, 0, s));
+    MM_TRY(run_layer(h->conv[1], a0, N, 48, 48, 64, 0, cat, 88, 0, nullptr, 0, s));
+    MM_TRY(run_layer(h->conv[2], cat, N, 24, 24, 88, 0, a1, 128, 0, nullptr, 0, s));
+    MM_TRY(run_layer(h->conv[3], a1, N, 24, 24, 128, 0, a2, 128, 0, nullptr, 0, s));
+    MM_TRY(run_layer(h->conv[4], a2, N, 12, 12, 128, 0, a3, 256, 0, nullptr, 0, s));
+    MM_TRY(run_layer(h->conv[5], a3, N, 12, 12, 256, 0, a4, 256, 0, nullptr, 0, s));
+    MM_TRY(avgpool_hw(a4, pool, N64, 36, 256, 256, 0, 0, s));
+    MM_TRY(run_layer(h->fc1, pool, N, 1, 1, 256, 0, fc1, 256, 0, nullptr, 0, s));
+    MM_TRY(run_layer(h->fc2, fc1, N, 1, 1, 256, 0, feat, 512, 256, nullptr, 0, s));  // cat([spatial, temporal]) (:136)
+    // ---- spatial stream: MLP (:22-26)
+    MM_TRY(run_layer(h->mlp1, rgb, N, 1, 1, 2048, 0, m1, 256, 0, nullptr, 0, s));
+    MM_TRY(run_layer(h->mlp2, m1, N, 1, 1, 256, 0, feat, 512, 0, nullptr, 0, s));
+    MM_TRY(run_layer(h->transform, feat, N, 1, 1, 512, 0, f, 256, 0, nullptr, 0, s));
+    // ---- nn.GRU(256,128,bidirectional,num_layers=2) WITHOUT batch_first: the [bs,T,256] tensor is read as
+    //      (seq_len = bs, batch = T)  (:119,139 -- quirk Q1, trained in, reproduced on purpose)
+    const int Ti = (int)T, S = (int)bs;
+    const float* x = f;
+    float* lay[2] = {l0, l1};
+    for (int l = 0; l < 2; ++l) {
+        MM_TRY(run_layer(h->gru_ih[l], x, N, 1, 1, 256, 0, gi, 768, 0, nullptr, 0, s));
+        for (int d = 0; d < 2; ++d) {
+            for (int step = 0; step < S; ++step) {
+                const int t = d == 0 ? step : S - 1 - step;
+                float* hout = lay[l] + (int64_t)t * Ti * 256;
+                const float* git = gi + (int64_t)t * Ti * 768;
+                if (step == 0) {
+                    MM_TRY(gru_gates(git, 768, d * 384, nullptr, h->bhh[l][d], nullptr, 0, 0, hout, 256, d * 128, Ti, 128, s));
+                } else {
+                    const int tp = d == 0 ? t - 1 : t + 1;
+                    const float* hprev = lay[l] + (int64_t)tp * Ti * 256;
+                    MM_TRY(run_layer(h->gru_hh[l][d], hprev, Ti, 1, 1, 256, d * 128, gh, 384, 0, nullptr, 0, s));
+                    MM_TRY(gru_gates(git, 768, d * 384, gh, nullptr, hprev, 256, d * 128, hout, 256, d * 128, Ti, 128, s));
+                }
+            }
+        }
+        x = lay[l];
+    }
+    MM_TRY(run_layer(h->classifier, l1, N, 1, 1, 256, 0, out, 2, 0, nullptr, 0, s));
+#undef MM_TRY
+    return MM_OK;
+}
+
+}  // extern "C"

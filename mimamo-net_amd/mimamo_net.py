@@ -1,0 +1,132 @@
+"""Two_Stream_RNN on MI355X -- drop-in for api/mimamo_net.py:96-143 (inference / eval mode).
+
+Same constructor arguments, `load_state_dict` with the reference's 107-tensor key layout, `.eval()`,
+`.to(device)`, `.forward([phase_0, phase_1], rgb) -> [bs, T, 2]`.  The forward pass runs in
+libmimamo_hip.so (fp32 MFMA conv engine + GRU kernels); there is no PyTorch compute path.
+"""
+import ctypes
+
+import torch
+
+from . import _lib, weights
+
+
+class Two_Stream_RNN(object):
+    def __init__(self, mlp_hidden_units=[2048, 256, 256], dropout=0.5, label_name='arousal_valence', num_phase=12):
+        if list(mlp_hidden_units) != [2048, 256, 256] or label_name != 'arousal_valence' or num_phase != 12:
+            raise NotImplementedError("this build implements the published configuration "
+                                      "(mlp [2048,256,256], arousal_valence, num_phase=12; api/tester.py:45)")
+        self.num_phase = num_phase
+        self.training = False
+        self._handle = None
+        self._state = None
+        self._ws = None
+        self.device = None
+
+    # -- nn.Module-like surface used by api/tester.py:45-51,77 ---------------------------------
+    def state_dict(self):
+        return dict(self._state) if self._state is not None else {}
+
+    def load_state_dict(self, state_dict, strict=True):
+        keys = weights.two_stream_float_keys()
+        missing = [k for k in keys if k not in state_dict]
+        if missing:
+            raise RuntimeError("Error(s) in loading state_dict for Two_Stream_RNN: Missing key(s): %s" % missing[:4])
+        if strict:
+            known = set(keys) | {k + ".num_batches_tracked" for k in weights.TWO_STREAM_BN_KEYS}
+            extra = [k for k in state_dict if k not in known]
+            if extra:
+                raise RuntimeError("Error(s) in loading state_dict for Two_Stream_RNN: Unexpected key(s): %s" % extra[:4])
+        self._state = {k: v for k, v in state_dict.items()}
+        self._blob = weights.two_stream_blob(state_dict)
+        self._release()
+        return self
+
+    def load_model_weights(self, model, model_path):  # api/mimamo_net.py:123-128
+        ckp = torch.load(model_path, map_location='cpu')
+        net_key = [key for key in ckp.keys() if (key != 'epoch') and (key != 'iter')][0]
+        model.load_state_dict(ckp[net_key])
+        return model
+
+    def eval(self):
+        self.training = False
+        return self
+
+    def train(self, mode=True):
+        if mode:
+            raise NotImplementedError("training is out of scope (inference hot path only)")
+        return self
+
+    def to(self, device):
+        device = torch.device(device)
+        if device.type != 'cuda':
+            raise RuntimeError("Two_Stream_RNN (HIP) only runs on a ROCm device; there is no CPU path")
+        if self.device != device:
+            self._release()
+        self.device = device
+        return self
+
+    def cuda(self):
+        return self.to(torch.device('cuda', torch.cuda.current_device()))
+
+    def _release(self):
+        if self._handle is not None:
+            _lib.lib().mm_head_destroy(self._handle)
+            self._handle = None
+
+    def __del__(self):
+        try:
+            self._release()
+        except Exception:
+            pass
+
+    def _get(self):
+        if self._handle is None:
+            if self._state is None:
+                raise RuntimeError("load_state_dict() first: there is no default-initialised HIP model")
+            if self.device is None:
+                self.device = torch.device('cuda', torch.cuda.current_device())
+            h = ctypes.c_void_p()
+            with torch.cuda.device(self.device):
+                rc = _lib.lib().mm_head_create(ctypes.byref(h), self._blob.ctypes.data_as(ctypes.c_void_p), self._blob.size)
+            _lib.check(rc, "mm_head_create")
+            self._handle = h
+        return self._handle
+
+    # -- forward ---------------------------------------------------------------------------------
+    def forward(self, phase_data, rgb_data, phase_layout="nchw"):
+        """phase_data = [phase_0 [bs,T,24,48,48], phase_1 [bs,T,24,24,24]], rgb_data [bs,T,2048] -> [bs,T,2].
+
+        phase_layout: "nchw" (reference), "nhwc" ([bs*T,48,48,24] / [bs*T,24,24,24]) or "nhwc_cat"
+        (phase_1 already at channels 64..87 of a [bs*T,24,24,88] buffer, completed in place).
+        The GRU recurrence runs over dim 0 (bs) with T as its batch (api/mimamo_net.py:119,139)."""
+        if self.training:
+            raise NotImplementedError("training mode")
+        h = self._get()
+        phase_0, phase_1 = phase_data
+        bs, T = rgb_data.size(0), rgb_data.size(1)
+        for t in (phase_0, phase_1, rgb_data):
+            if not t.is_cuda:
+                raise RuntimeError("inputs must be on the ROCm device; this build has no CPU path")
+            assert t.dtype == torch.float32
+        mode = {"nchw": 0, "nhwc": 1, "nhwc_cat": 2}[phase_layout]
+        if mode == 0:
+            assert tuple(phase_0.shape) == (bs, T, 24, 48, 48) and tuple(phase_1.shape) == (bs, T, 24, 24, 24)
+        elif mode == 1:
+            assert tuple(phase_0.shape) == (bs * T, 48, 48, 24) and tuple(phase_1.shape) == (bs * T, 24, 24, 24)
+        else:
+            assert tuple(phase_0.shape) == (bs * T, 48, 48, 24) and tuple(phase_1.shape) == (bs * T, 24, 24, 88)
+        assert rgb_data.size(2) == 2048
+        phase_0, phase_1, rgb = phase_0.contiguous(), phase_1.contiguous(), rgb_data.contiguous()
+        out = torch.empty((bs, T, 2), dtype=torch.float32, device=rgb.device)
+        L = _lib.lib()
+        need = L.mm_head_workspace_bytes(h, bs, T)
+        if self._ws is None or self._ws.numel() * 4 < need:
+            self._ws = None
+            self._ws = torch.empty(((need + 3) // 4,), dtype=torch.float32, device=rgb.device)
+        rc = L.mm_head_forward(h, _lib.ptr(phase_0), _lib.ptr(phase_1), mode, _lib.ptr(rgb), bs, T, _lib.ptr(out),
+                               _lib.ptr(self._ws), need, _lib.current_stream())
+        _lib.check(rc, "mm_head_forward")
+        return out
+
+    __call__ = forward

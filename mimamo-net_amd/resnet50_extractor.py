@@ -1,0 +1,104 @@
+"""Resnet50_Extractor on MI355X -- drop-in for api/resnet50_extractor.py:13-88.
+
+The reference loads a third-party model definition + weights by name
+(`pytorch-benchmarks/ferplus/resnet50_ferplus_dag.{py,pth}`, api/utils/model_utils.py:65-79) and hooks
+layer `pool5_7x7_s1`.  That dependency is not vendored; here the same Caffe-style ResNet-50 trunk runs on
+the fp32 MFMA conv engine of libmimamo_hip.so, with weights taken from a state_dict in the third-party
+file's key layout (`conv1_7x7_s2.weight`, `conv1_7x7_s2_bn.{weight,bias,running_mean,running_var}`, ...).
+"""
+import ctypes
+import os
+
+import numpy as np
+import torch
+
+from . import _lib, weights
+
+
+class Resnet50_Extractor(object):
+    def __init__(self, benchmark_dir='pytorch-benchmarks', model_name='resnet50_ferplus_dag',
+                 feature_layer='pool5_7x7_s1', state_dict=None, device=None):
+        """benchmark_dir/model_name/feature_layer as api/resnet50_extractor.py:14-15.
+
+        state_dict: weights in the third-party key layout.  If None, `<benchmark_dir>/ferplus/<model_name>.pth`
+        is loaded when it exists (the reference's location, api/resnet50_extractor.py:35-36); otherwise the
+        constructor asserts like the reference does (:33)."""
+        if feature_layer != 'pool5_7x7_s1':
+            raise NotImplementedError("only the pool5_7x7_s1 hook of the reference is implemented")
+        self.benchmark_dir = os.path.abspath(benchmark_dir)
+        self.model_name = model_name
+        self.feature_layer = feature_layer
+        if state_dict is None:
+            assert os.path.exists(self.benchmark_dir), 'benchmark_dir must exits'
+            pth = os.path.join(self.benchmark_dir, 'ferplus', model_name + '.pth')
+            state_dict = torch.load(pth, map_location='cpu')
+        self.meta = {'mean': list(weights.RESNET50_MEAN), 'std': [1, 1, 1], 'imageSize': [224, 224, 3]}
+        self.device = torch.device('cuda', torch.cuda.current_device()) if device is None else torch.device(device)
+        blob = weights.resnet50_blob(state_dict)
+        h = ctypes.c_void_p()
+        L = _lib.lib()
+        with torch.cuda.device(self.device):
+            rc = L.mm_resnet50_create(ctypes.byref(h), blob.ctypes.data_as(ctypes.c_void_p), blob.size, 1, 1, 1e-5)
+        _lib.check(rc, "mm_resnet50_create")
+        self._handle = h
+        self._ws = None
+
+    def close(self):
+        if getattr(self, "_handle", None) is not None:
+            _lib.lib().mm_resnet50_destroy(self._handle)
+            self._handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _workspace(self, bs):
+        need = _lib.lib().mm_resnet50_workspace_bytes(self._handle, bs)
+        if self._ws is None or self._ws.numel() * 4 < need:
+            self._ws = None
+            self._ws = torch.empty(((need + 3) // 4,), dtype=torch.float32, device=self.device)
+        return self._ws, need
+
+    def get_vec(self, image, channels_last4=False):
+        """image [bs,3,224,224] (255*x - mean) -> pool5 features [bs,2048] ON THE DEVICE.
+
+        (api/resnet50_extractor.py:74-83 returns relu(squeeze()) of a CPU copy; squeeze() collapsing bs=1 and
+        the host copy are quirk Q8 and are not reproduced.)  channels_last4=True takes [bs,224,224,4]."""
+        if not image.is_cuda:
+            raise RuntimeError("image must be on the ROCm device; this build has no CPU path")
+        assert image.dtype == torch.float32
+        bs = image.size(0)
+        assert tuple(image.shape[1:]) == ((224, 224, 4) if channels_last4 else (3, 224, 224))
+        image = image.contiguous()
+        out = torch.empty((bs, 2048), dtype=torch.float32, device=image.device)
+        ws, need = self._workspace(bs)
+        rc = _lib.lib().mm_resnet50_forward(self._handle, _lib.ptr(image), 0 if channels_last4 else 1, bs,
+                                            _lib.ptr(out), _lib.ptr(ws), need, _lib.current_stream())
+        _lib.check(rc, "mm_resnet50_forward")
+        return out
+
+    def run(self, input_dir, output_dir, batch_size=64, video_name=''):
+        """Write one `%05d.npy` (f32[2048]) per aligned face `frame_det_00_%06d.bmp` (api/resnet50_extractor.py:42-73);
+        skipped when output_dir already holds .npy files (:61-65)."""
+        from .sampler import list_aligned_frames, load_rgb_batch
+        assert os.path.exists(input_dir), 'input dir must exsit!'
+        assert len(os.listdir(input_dir)) != 0, 'input dir must not be empty!'
+        assert len(video_name) != 0, 'input video name cannot be empty!'
+        if not os.path.exists(output_dir):
+            os.makedirs(output_dir)
+        elif len(os.listdir(output_dir)) != 0 and '.npy' in os.listdir(output_dir)[0]:
+            print("output_dir {} already exists, feature extraction skipped.".format(output_dir))
+            return
+        frames = list_aligned_frames(input_dir, video_name)
+        for i in range(0, len(frames), batch_size):
+            chunk = frames[i:i + batch_size]
+            ims = load_rgb_batch([p for _, p in chunk], self.meta['mean']).to(self.device)
+            feats = self.get_vec(ims).cpu().numpy()
+            for (idx, _), f in zip(chunk, feats):
+                np.save(os.path.join(output_dir, "%05d.npy" % idx), f)
+
+    @staticmethod
+    def get_frame_index(frame_path):
+        return int(os.path.basename(frame_path).split('.')[0].split('_')[-1])

@@ -145,3 +145,42 @@ def make_resnet50_state_dict(seed=0):
         damp = name.endswith("1x1_increase") or name.endswith("1x1_proj")
         _bn(sd, name + "_bn", cout, seed, gamma=(0.35, 0.55) if damp else (0.8, 1.2))
     return sd
+
+
+# ---------------------------------------------------------------------------------------------
+# Weight blobs handed to the C ABI (mm_resnet50_create / mm_head_create): flat float32 arrays,
+# tensors concatenated in a fixed order.
+# ---------------------------------------------------------------------------------------------
+def _np(v):
+    if hasattr(v, "detach"):
+        v = v.detach().cpu().numpy()
+    return np.ascontiguousarray(np.asarray(v), dtype=np.float32).ravel()
+
+
+def resnet50_blob(state_dict):
+    """Per layer of resnet50_layers(): conv weight (OIHW), then BN weight, bias, running_mean, running_var."""
+    parts = []
+    for name, cin, cout, k, _, _ in resnet50_layers():
+        w = _np(state_dict[name + ".weight"])
+        assert w.size == cout * cin * k * k, name
+        if (name + ".bias") in state_dict:
+            raise NotImplementedError("conv bias in the ResNet50 trunk (the third-party model has none)")
+        parts.append(w)
+        for s in ("weight", "bias", "running_mean", "running_var"):
+            parts.append(_np(state_dict[name + "_bn." + s]))
+    return np.concatenate(parts)
+
+
+TWO_STREAM_FLOAT_KEYS = None
+
+
+def two_stream_float_keys():
+    """state_dict keys of Two_Stream_RNN in module order, without the int64 BN counters."""
+    global TWO_STREAM_FLOAT_KEYS
+    if TWO_STREAM_FLOAT_KEYS is None:
+        TWO_STREAM_FLOAT_KEYS = [k for k in make_two_stream_state_dict(0) if not k.endswith("num_batches_tracked")]
+    return TWO_STREAM_FLOAT_KEYS
+
+
+def two_stream_blob(state_dict):
+    return np.concatenate([_np(state_dict[k]) for k in two_stream_float_keys()])

@@ -1,0 +1,189 @@
+"""GPU parity: fp32 MFMA conv engine, two-stream head and ResNet50 pool5 (through the C ABI) vs the oracle
+(torch fp32 CPU restatement) and the golden head outputs frozen from the real reference."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from mimamo_net_amd import weights
+
+pytestmark = pytest.mark.gpu
+
+OUT_ATOL = 1e-4        # valence/arousal tolerance stated by BASELINE.json north_star
+POOL5_RTOL = 1e-5      # pool5 features, relative to the feature scale
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+def _pack(w):
+    """OIHW -> [Cout][Kpad], k = (r*kw+s)*Cin + c."""
+    co, ci, kh, kw = w.shape
+    k = kh * kw * ci
+    kp = (k + 15) // 16 * 16
+    out = np.zeros((co, kp), dtype=np.float32)
+    out[:, :k] = w.transpose(0, 2, 3, 1).reshape(co, k)
+    return out
+
+
+CASES = [
+    # B, H, W, Cin, Cout, k, stride, pad, relu, tile
+    (2, 14, 14, 64, 64, 1, 1, 0, 1, 0),
+    (2, 14, 14, 64, 96, 3, 1, 1, 1, 3),
+    (3, 15, 13, 24, 40, 3, 2, 1, 0, 0),      # ragged M/N, K = 216 (not a multiple of 16), odd sizes
+    (1, 23, 23, 4, 64, 7, 2, 3, 1, 2),       # stem-like, Cin = 4
+    (2, 9, 9, 128, 256, 1, 2, 0, 0, 1),      # strided 1x1 (projection shortcut)
+    (5, 1, 1, 2048, 256, 1, 1, 0, 1, 0),     # Linear
+    (4, 28, 28, 128, 128, 3, 1, 1, 1, 1),    # 128x128 tiles, several m tiles
+    (2, 12, 12, 88, 128, 3, 1, 1, 1, 2),     # K = 792
+]
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_conv_engine_vs_torch(pkg, dev, case):
+    from mimamo_net_amd import _lib
+    B, H, W, Ci, Co, k, st, pad, relu, tile = case
+    x = weights.det_uniform("cx", (B, Ci, H, W), -1, 1, 1)
+    w = weights.det_uniform("cw", (Co, Ci, k, k), -1, 1, 2) / np.sqrt(Ci * k * k).astype(np.float32)
+    b = weights.det_uniform("cb", (Co,), -0.5, 0.5, 3)
+    ref = F.conv2d(torch.from_numpy(x).double(), torch.from_numpy(w).double(), torch.from_numpy(b).double(), stride=st, padding=pad)
+    Ho, Wo = ref.shape[2], ref.shape[3]
+    res = weights.det_uniform("cr", (B, Co, Ho, Wo), -1, 1, 4)
+    ps = weights.det_uniform("cps", (Co,), 0.5, 1.5, 5)
+    pt = weights.det_uniform("cpt", (Co,), -0.5, 0.5, 6)
+    ref = ref + torch.from_numpy(res).double()
+    if relu:
+        ref = F.relu(ref)
+    ref = (ref * torch.from_numpy(ps).double()[None, :, None, None] + torch.from_numpy(pt).double()[None, :, None, None]).numpy()
+    # channel-sliced input (offset 4 in a wider buffer) and channel-offset output, like the PhaseNet concat
+    xin = torch.zeros(B, H, W, Ci + 8)
+    xin[..., 4:4 + Ci] = torch.from_numpy(x).permute(0, 2, 3, 1)
+    xin = xin.to(dev)
+    out = torch.full((B, Ho, Wo, Co + 5), -7.0, device=dev)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    wd, bd, rd, psd, ptd = t(_pack(w)), t(b), t(res.transpose(0, 2, 3, 1)), t(ps), t(pt)
+    rc = _lib.lib().mm_conv2d_nhwc(_lib.ptr(xin), _lib.ptr(wd), _lib.ptr(bd), _lib.ptr(rd), _lib.ptr(psd), _lib.ptr(ptd),
+                                   _lib.ptr(out), B, H, W, Ci, Ci + 8, 4, Co, Co + 5, 5, Co, k, k, st, pad, relu, tile,
+                                   _lib.current_stream())
+    assert rc == 0
+    got = out.cpu().numpy()
+    assert (got[..., :5] == -7.0).all()  # nothing outside the channel window is touched
+    err = np.abs(got[..., 5:].transpose(0, 3, 1, 2) - ref).max()
+    assert err < 2e-5, err
+
+
+def _head_inputs(bs, t, seed):
+    p0 = weights.det_uniform("head.p0", (bs, t, 24, 48, 48), -1.5, 1.5, seed)
+    p1 = weights.det_uniform("head.p1", (bs, t, 24, 24, 24), -1.5, 1.5, seed)
+    rgb = weights.det_uniform("head.rgb", (bs, t, 2048), 0.0, 2.0, seed)
+    return p0, p1, rgb
+
+
+@pytest.fixture(scope="module")
+def head(pkg, dev):
+    from mimamo_net_amd.mimamo_net import Two_Stream_RNN
+    m = Two_Stream_RNN()
+    m.load_state_dict(weights.make_two_stream_state_dict(seed=3))
+    return m.eval().to(dev)
+
+
+@pytest.mark.parametrize("bs", [1, 3])
+def test_head_golden_reference_outputs(head, golden, dev, bs):
+    """Against outputs of the REAL reference Two_Stream_RNN (incl. the GRU seq-over-dim-0 quirk at bs=3)."""
+    g = golden("head")
+    p0, p1, rgb = _head_inputs(bs, 4, int(g["in_seed_bs%d" % bs]))
+    y = head([torch.from_numpy(p0).to(dev), torch.from_numpy(p1).to(dev)], torch.from_numpy(rgb).to(dev)).cpu().numpy()
+    assert y.shape == (bs, 4, 2)
+    err = np.abs(y - g["out_bs%d" % bs]).max()
+    assert err < OUT_ATOL, err
+    assert err < 2e-5, err  # in practice fp32 round-off only
+
+
+def test_head_full_clip_vs_oracle_and_layouts(head, oracle, dev):
+    sd = weights.make_two_stream_state_dict(seed=3)
+    for bs, T in ((1, 64), (2, 64)):
+        p0, p1, rgb = _head_inputs(bs, T, 70 + bs)
+        want = oracle.two_stream_forward(sd, p0, p1, rgb)
+        tp0, tp1, trgb = (torch.from_numpy(a).to(dev) for a in (p0, p1, rgb))
+        y = head([tp0, tp1], trgb)
+        assert np.abs(y.cpu().numpy() - want).max() < 2e-5
+        # channels-last entry points give the same bits
+        n0 = tp0.reshape(bs * T, 24, 48, 48).permute(0, 2, 3, 1).contiguous()
+        n1 = tp1.reshape(bs * T, 24, 24, 24).permute(0, 2, 3, 1).contiguous()
+        assert torch.equal(head.forward([n0, n1], trgb, phase_layout="nhwc"), y)
+        cat = torch.zeros(bs * T, 24, 24, 88, device=dev)
+        cat[..., 64:] = n1
+        assert torch.equal(head.forward([n0, cat], trgb, phase_layout="nhwc_cat"), y)
+
+
+def test_head_bs1_is_frame_permutation_equivariant(head, dev):
+    """With bs=1 the GRU sees seq_len 1: frames are independent."""
+    p0, p1, rgb = (torch.from_numpy(a).to(dev) for a in _head_inputs(1, 16, 5))
+    perm = torch.randperm(16, device=dev)
+    y = head([p0, p1], rgb)
+    yp = head([p0[:, perm].contiguous(), p1[:, perm].contiguous()], rgb[:, perm].contiguous())
+    assert torch.equal(yp, y[:, perm])
+
+
+def test_head_state_dict_errors(pkg, dev):
+    from mimamo_net_amd.mimamo_net import Two_Stream_RNN
+    sd = weights.make_two_stream_state_dict(seed=1)
+    m = Two_Stream_RNN()
+    bad = dict(sd)
+    bad.pop("transform.0.weight")
+    with pytest.raises(RuntimeError, match="Missing key"):
+        m.load_state_dict(bad)
+    bad = dict(sd)
+    bad["bogus.weight"] = np.zeros(3, dtype=np.float32)
+    with pytest.raises(RuntimeError, match="Unexpected key"):
+        m.load_state_dict(bad)
+    with pytest.raises(RuntimeError):
+        Two_Stream_RNN().forward([torch.zeros(1), torch.zeros(1)], torch.zeros(1, 1, 2048, device=dev))
+
+
+@pytest.fixture(scope="module")
+def resnet(pkg, dev):
+    from mimamo_net_amd.resnet50_extractor import Resnet50_Extractor
+    return Resnet50_Extractor(state_dict=weights.make_resnet50_state_dict(seed=0), device=dev)
+
+
+def _images(n, seed):
+    # 255*x - mean with x in [0,1): same range as the reference's transform (utils/model_utils.py:36-39)
+    x = weights.det_uniform("rs.img", (n, 3, 224, 224), 0.0, 255.0, seed)
+    return x - np.asarray(weights.RESNET50_MEAN, dtype=np.float32)[None, :, None, None]
+
+
+def test_resnet50_pool5_vs_oracle(resnet, oracle, dev):
+    x = _images(3, 1)
+    want = oracle.resnet50_pool5(weights.make_resnet50_state_dict(seed=0), x)
+    got = resnet.get_vec(torch.from_numpy(x).to(dev))
+    assert tuple(got.shape) == (3, 2048) and got.is_cuda
+    got = got.cpu().numpy()
+    scale = np.abs(want).max()
+    rel = np.abs(got - want).max() / scale
+    assert rel < POOL5_RTOL * 10, rel          # hard bound
+    assert np.abs(got - want).mean() / scale < POOL5_RTOL, np.abs(got - want).mean() / scale
+    assert (got >= 0).all() and got.std() > 0
+    # batch composition does not change a frame's features (no cross-frame coupling, tile choice aside)
+    one = resnet.get_vec(torch.from_numpy(x[1:2]).to(dev)).cpu().numpy()
+    assert np.abs(one[0] - got[1]).max() / scale < 1e-5
+    # channels-last (padded to 4) entry point
+    x4 = np.zeros((3, 224, 224, 4), dtype=np.float32)
+    x4[..., :3] = x.transpose(0, 2, 3, 1)
+    got4 = resnet.get_vec(torch.from_numpy(x4).to(dev), channels_last4=True).cpu().numpy()
+    np.testing.assert_array_equal(got4, got)
+
+
+def test_resnet50_full_batch_properties(resnet, dev):
+    """BASELINE config 3 size (batch 64): finite, deterministic, batch-invariant."""
+    x = torch.from_numpy(_images(64, 2)).to(dev)
+    a = resnet.get_vec(x)
+    b = resnet.get_vec(x)
+    assert torch.isfinite(a).all() and torch.equal(a, b)
+    sub = resnet.get_vec(x[10:14].contiguous())
+    assert (sub - a[10:14]).abs().max() / a.abs().max() < 1e-5
