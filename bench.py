@@ -1,0 +1,196 @@
+#!/usr/bin/env python
+"""bench.py -- end-to-end throughput of the MIMAMO-Net per-video inference hot path on MI355X.
+
+Metric (BASELINE.json): face-frames/sec end-to-end (phase-diff + ResNet50 + 2-stream GRU), 64-frame clips.
+Workload at N=1 (BASELINE configs[3]): a batch of independent 64-frame clips, full two-stream path
+(steerable pyramid + phase difference, ResNet50 pool5, PhaseNet/MLP/GRU head), fp32, random-init weights of
+the reference architecture, synthetic 112x112 aligned-face clips preprocessed to the tensors the reference's
+hot path consumes (gray 48x48 in [0,1]; RGB 224x224 = 255x-mean), resident in HBM before the timed region.
+One step = one pass of the hot path over `--clips` clips (default 8 -> 512 frames) per GPU.
+
+N>1: one process per GPU (torch.distributed, backend nccl = RCCL), clips sharded across ranks (weak scaling,
+`--clips` per rank), no data-path collective; per-clip results are all-gathered (8 B/frame) inside the timed
+region; the time is the max over ranks.
+
+Prints ONE JSON line (rank 0) with `roofline` (conv/GEMM engine on the fp32 matrix cores, timed live with
+hipEvents on the launch stream by the library's measurement hook) and `cpu_baseline` (the oracle's
+PyTorch-CPU restatement of the same path on a bounded sample, rank 0 / N=1 only).
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CU x 4 SIMD x 64 FLOP/clk x 2.4 GHz
+PEAK_HBM_GBS = 8000.0
+FRAMES_PER_CLIP = 64
+
+
+def make_inputs(n_clips, rank, device):
+    """Synthetic clips -> the hot path's input tensors on the device (data prep is outside the timed region)."""
+    from mimamo_net_amd import synthetic
+    grays, rgbs = [], []
+    for c in range(n_clips):
+        clip = synthetic.make_clip_u8(rank * n_clips + c, FRAMES_PER_CLIP)
+        g, r = synthetic.preprocess_host(clip)
+        grays.append(g)
+        rgbs.append(r)
+    gray = torch.from_numpy(np.concatenate(grays)).to(device)
+    rgb = torch.from_numpy(np.concatenate(rgbs)).to(device)
+    return gray, rgb
+
+
+def cpu_baseline(n_frames, head_sd, resnet_sd):
+    """Oracle (reference-semantics PyTorch-CPU restatement incl. the 13x redundant pyramid) on one clip."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import mm_oracle
+    from mimamo_net_amd import synthetic, sampler
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    clip = synthetic.make_clip_u8(0, n_frames)
+    gray, rgb = synthetic.preprocess_host(clip)
+    ids = sampler.window_ids(0, n_frames, n_frames)
+    t0 = time.time()
+    p0, p1 = mm_oracle.phase_diff_output(gray[ids][None])           # tester.py:122-139 (windowed, 13x redundant)
+    t1 = time.time()
+    feats = mm_oracle.resnet50_pool5(resnet_sd, rgb)                # resnet50_extractor.py:74-83
+    t2 = time.time()
+    out = mm_oracle.two_stream_forward(head_sd, p0, p1, feats[None])  # mimamo_net.py:129-143
+    t3 = time.time()
+    total = t3 - t0
+    return {"value": n_frames / total, "unit": "frames/s", "cores": cores, "kind": "port",
+            "sample": "1 clip x %d frames, oracle/mm_oracle.py on PyTorch-CPU fp32 (phase %.2fs, resnet50 %.2fs, head %.2fs)"
+                      % (n_frames, t1 - t0, t2 - t1, t3 - t2)}, out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--clips", type=int, default=8, help="64-frame clips per GPU per step")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-frames", type=int, default=64)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world)
+    else:
+        torch.cuda.set_device(0)
+    device = torch.device("cuda", torch.cuda.current_device())
+
+    import mimamo_net_amd  # noqa: F401
+    from mimamo_net_amd import _lib, weights
+    from mimamo_net_amd.pipeline import HotPath
+
+    head_sd = weights.make_two_stream_state_dict(seed=0)
+    resnet_sd = weights.make_resnet50_state_dict(seed=0)
+    hot = HotPath(head_sd, resnet_sd, device)
+    gray, rgb = make_inputs(args.clips, rank, device)
+    plan = hot.plan([FRAMES_PER_CLIP] * args.clips)
+    n_frames = args.clips * FRAMES_PER_CLIP
+
+    def step():
+        out = hot.forward(gray, rgb, plan, independent_clips=True)  # [frames, 2]
+        if world > 1:
+            import torch.distributed as dist
+            gathered = [torch.empty_like(out) for _ in range(world)]
+            dist.all_gather(gathered, out)
+        return out
+
+    def fence():
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    with torch.no_grad():
+        for _ in range(args.warmup):
+            out = step()
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            out = step()
+        fence()
+        dt = time.perf_counter() - t0
+    if world > 1:
+        import torch.distributed as dist
+        t = torch.tensor([dt], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    assert torch.isfinite(out).all()
+
+    # ---- roofline leg: hipEvent-timed launches of one more step (same stream), by kernel category
+    L = _lib.lib()
+    ms = (ctypes.c_double * 3)()
+    work = (ctypes.c_double * 3)()
+    launches = (ctypes.c_int64 * 3)()
+    with torch.no_grad():
+        L.mm_profile_begin()
+        step()
+        rc = L.mm_profile_end(ms, work, launches)
+    assert rc == 0
+    conv_tflops = work[0] / (ms[0] * 1e-3) / 1e12
+    phase_ms = ms[1] + ms[2]
+    phase_gbs = (work[1] + work[2]) / (phase_ms * 1e-3) / 1e9
+
+    result = {
+        "metric": "face-frames/sec end-to-end (phase-diff + ResNet50 + 2-stream GRU), 64-frame clips",
+        "value": world * n_frames * args.steps / dt,
+        "unit": "frames/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": dt / args.steps * 1e3,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {"workload": "full two-stream hot path (BASELINE configs[3]): %d clips x 64 frames per GPU per step; "
+                               "gray 48x48 + RGB 224x224 fp32 resident in HBM; random-init weights of the reference architecture"
+                               % args.clips,
+                   "clips_per_gpu": args.clips, "frames_per_step_per_gpu": n_frames, "parallelism": "videos sharded, dp%d" % world},
+        "roofline": {"bound": "mfma", "kernel": "conv_mfma_kernel (fp32 implicit-GEMM conv/GEMM engine, all %d launches of one step)" % launches[0],
+                     "achieved": conv_tflops, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                     "frac": conv_tflops / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
+                     "flops_per_step": work[0], "ms_per_step": ms[0], "launches_per_step": int(launches[0])},
+        "roofline_phase": {"bound": "hbm", "kernel": "pyramid_kernel + phase_window_kernel<48|24>",
+                           "achieved": phase_gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": phase_gbs / PEAK_HBM_GBS,
+                           "traffic": None, "bytes_per_step": work[1] + work[2], "ms_per_step": phase_ms,
+                           "ms_pyramid": ms[1], "ms_window": ms[2]},
+    }
+    if rank == 0:
+        if world == 1 and not args.no_cpu_baseline:
+            cb, cpu_out = cpu_baseline(args.cpu_frames, head_sd, resnet_sd)
+            result["cpu_baseline"] = cb
+            # the CPU sample is clip 0 of this rank: report the parity of the two paths next to the numbers
+            if args.cpu_frames == FRAMES_PER_CLIP:
+                gpu0 = out[:FRAMES_PER_CLIP].cpu().numpy()
+                result["parity_vs_cpu_sample"] = {"max_abs_err_valence_arousal": float(np.abs(gpu0 - cpu_out[0]).max()),
+                                                  "tolerance": 1e-4}
+        else:
+            result["cpu_baseline"] = None
+        print(json.dumps(result))
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

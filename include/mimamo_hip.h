@@ -162,6 +162,17 @@ int mm_head_forward(mm_head_t* h, const float* phase_0, const float* phase_1, in
                     const float* rgb, int64_t bs, int64_t T, float* out,
                     void* workspace, int64_t workspace_bytes, void* stream);
 
+/* ---------------------------------------------------------------------------------------
+ * Measurement hook (bench.py roofline leg; not part of the reference surface).  Between begin and
+ * end every kernel launch is bracketed by hipEvents on its own stream.  Categories: 0 conv/GEMM
+ * engine (work = algorithmic FLOPs 2*M*K*Cout), 1 pyramid kernel, 2 phase-window kernel (work =
+ * algorithmic HBM bytes: frame in / phase planes out).  Arrays hold MM_PROF_CATEGORIES entries.
+ * mm_profile_end synchronises the device.
+ * ------------------------------------------------------------------------------------- */
+#define MM_PROF_CATEGORIES 3
+int mm_profile_begin(void);
+int mm_profile_end(double* ms, double* work, int64_t* launches);
+
 #ifdef __cplusplus
 }
 #endif

@@ -19,6 +19,7 @@ struct ConvParams {
     int K, Kpad;
     int relu;
     int force_tile;  // 0 auto, 1 = 128x128, 2 = 128x64, 3 = 64x64
+    int Cin_real;    // un-padded input channels (FLOP accounting only; 0 = Cin)
     int M, tiles_m, tiles_n;  // filled by conv_forward
 };
 

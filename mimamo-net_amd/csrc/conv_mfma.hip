@@ -181,7 +181,9 @@ static int launch_cfg(ConvParams p, hipStream_t stream) {
     p.tiles_n = (p.Cout + BN - 1) / BN;
     const int64_t blocks = (int64_t)p.tiles_m * p.tiles_n;
     if (blocks <= 0 || blocks > 0x7fffffff) return MM_ERR_INVALID_ARG;
+    prof_before(0, 2.0 * (double)p.M * (double)(p.kh * p.kw * p.Cin_real) * (double)p.Cout, stream);
     hipLaunchKernelGGL((conv_mfma_kernel<BM, BN>), dim3((unsigned)blocks), dim3(256), 0, stream, p);
+    prof_after(0, stream);
     MM_LAUNCH_CHECK();
     return MM_OK;
 }
@@ -191,6 +193,7 @@ int conv_forward(const ConvParams& p0, hipStream_t stream) {
     if (p.Cin % 4 || p.in_cstride % 4 || p.in_coff % 4 || p.Kpad % CBK || p.K > p.Kpad) return MM_ERR_INVALID_ARG;
     p.M = p.B * p.Ho * p.Wo;
     if (p.M <= 0) return MM_OK;
+    if (p.Cin_real <= 0) p.Cin_real = p.Cin;
     // tile choice: the largest tile that still gives every CU (256) a couple of workgroups
     const int64_t t128 = (int64_t)((p.M + 127) / 128) * ((p.Cout + 127) / 128);
     if (p.force_tile == 1 || (p.force_tile == 0 && p.Cout > 64 && t128 >= 512)) return launch_cfg<128, 128>(p, stream);

@@ -26,6 +26,11 @@ inline int hip_fail(hipError_t e) {
         if (_e != hipSuccess) return mm::hip_fail(_e); \
     } while (0)
 
+// ---- optional launch timing (profile.hip)
+bool prof_enabled();
+void prof_before(int cat, double work, hipStream_t s);
+void prof_after(int cat, hipStream_t s);
+
 // ---- host-side pyramid constants (mm_masks.cpp) -------------------------------------
 struct PyramidConfig {
     int size;          // un-mirrored side (48)

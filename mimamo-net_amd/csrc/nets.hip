@@ -96,7 +96,7 @@ static int run_layer(const Layer& L, const float* in, int B, int H, int W, int i
     p.Cout = L.cout; p.out_cstride = out_cstride; p.out_coff = out_coff;
     p.res_cstride = res_cstride; p.res_coff = 0;
     p.kh = L.k; p.kw = L.k; p.stride = L.stride; p.pad = L.pad;
-    p.K = L.K; p.Kpad = L.Kpad; p.relu = L.relu;
+    p.K = L.K; p.Kpad = L.Kpad; p.relu = L.relu; p.Cin_real = L.cin;
     if (Ho_) *Ho_ = p.Ho;
     if (Wo_) *Wo_ = p.Wo;
     return conv_forward(p, s);

@@ -204,6 +204,7 @@ int launch_phase_window(const float* coeff, const int32_t* ids, int64_t img_stri
         gauss_ready = true;
     }
     const dim3 grid((unsigned)(2 * J));
+    prof_before(2, (double)J * 2 * (P - 1) * W * W * 4, stream);  // algorithmic write: 24 phase-difference planes
     if (W == 48) {
         hipLaunchKernelGGL(phase_window_kernel<48>, grid, dim3(WinCfg<48>::NTHREADS), 0, stream, coeff, ids, img_stride,
                            band_stride, out, out_nhwc, out_cstride, out_coffset);
@@ -213,6 +214,7 @@ int launch_phase_window(const float* coeff, const int32_t* ids, int64_t img_stri
     } else {
         return MM_ERR_UNSUPPORTED;
     }
+    prof_after(2, stream);
     MM_LAUNCH_CHECK();
     return MM_OK;
 }

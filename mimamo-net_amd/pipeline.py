@@ -1,0 +1,78 @@
+"""Fused per-video inference pipeline on one MI355X: the build's counterpart of what api/tester.py
+wires together (Resnet50_Extractor.run -> Snippet_Sampler -> phase_diff_output -> Two_Stream_RNN),
+without the disk round trips (.npy features, re-opened BMPs) and without the 13x redundant pyramid.
+
+    gray frames [N,48,48] --pyramid (once per frame)--> window kernel --> phase_0 / phase_1 (NHWC)
+    rgb  frames [N,3,224,224] --ResNet50 trunk--> pool5 [N,2048]
+    head(phase_0, phase_1, pool5) per video (GRU over that video's snippets) --> [frames, 2]
+"""
+import numpy as np
+import torch
+
+from . import sampler
+from .mimamo_net import Two_Stream_RNN
+from .phase_difference_extractor import Phase_Difference_Extractor
+from .resnet50_extractor import Resnet50_Extractor
+
+
+class HotPath(object):
+    def __init__(self, head_state_dict, resnet_state_dict, device=None, length=64, stride=64, num_phase=12,
+                 batch_size=64):
+        self.device = torch.device('cuda', torch.cuda.current_device()) if device is None else torch.device(device)
+        self.length, self.stride, self.num_phase, self.batch_size = length, stride, num_phase, batch_size
+        self.pde = Phase_Difference_Extractor(4, 2, 2, [1, 2], False)
+        self.resnet = Resnet50_Extractor(state_dict=resnet_state_dict, device=self.device)
+        self.head = Two_Stream_RNN().load_state_dict(head_state_dict).eval().to(self.device)
+
+    # ---- index plan for a set of videos (host, once) ---------------------------------------------
+    def plan(self, video_lengths):
+        """Frames of all videos are stacked along dim 0.  Returns a dict with, per video, its snippet
+        ranges, and the global window-id table of every snippet frame (in snippet order)."""
+        ids, vids, off = [], [], 0
+        for n in video_lengths:
+            ranges = sampler.snippet_ranges(n, self.length, self.stride)
+            rows0 = sum(len(x) for x in ids)
+            for s, e in ranges:
+                ids.append(sampler.window_ids(s, e, n, self.num_phase) + off)
+            vids.append({"n": n, "offset": off, "ranges": ranges, "row0": rows0,
+                         "T": ranges[0][1] - ranges[0][0]})
+            off += n
+        ids = np.concatenate(ids, axis=0)
+        # frame index (global) of every snippet row = centre column of its window
+        return {"videos": vids, "ids": torch.from_numpy(ids).to(self.device).contiguous(),
+                "rows": torch.from_numpy(ids[:, self.num_phase // 2].astype(np.int64)).to(self.device), "n_frames": off}
+
+    # ---- one pass of the hot path ------------------------------------------------------------------
+    def forward(self, gray, rgb, plan, independent_clips=False):
+        """gray [N,48,48] f32, rgb [N,3,224,224] f32 (or NHWC4) on the device, `plan` from plan().
+        Returns [rows, 2] valence/arousal for every snippet row (snippet order).
+
+        independent_clips=True: every video is exactly one snippet of `length` frames, so each GRU call has
+        seq_len 1 and the calls are batched into one (identical results: GRU batch elements are independent)."""
+        J = plan["ids"].shape[0]
+        p0, cat = self.pde.phase_diff_frames(gray, plan["ids"], nhwc=True, out1_cstride=88, out1_coffset=64)
+        feats = self.resnet.get_vec(rgb, channels_last4=(rgb.dim() == 4 and rgb.shape[-1] == 4))  # [N,2048], per unique frame
+        rgb_rows = feats if J == feats.shape[0] and independent_clips else feats.index_select(0, plan["rows"])
+        if independent_clips:
+            out = self.head.forward([p0, cat], rgb_rows.view(1, J, 2048), phase_layout="nhwc_cat")
+            return out.view(J, 2)
+        outs = []
+        for v in plan["videos"]:
+            T, S = v["T"], len(v["ranges"])
+            for c0 in range(0, S, self.batch_size):  # DataLoader(batch_size) chunks (api/tester.py:69-72)
+                c1 = min(S, c0 + self.batch_size)
+                r0, r1 = v["row0"] + c0 * T, v["row0"] + c1 * T
+                o = self.head.forward([p0[r0:r1], cat[r0:r1]], rgb_rows[r0:r1].view(c1 - c0, T, 2048),
+                                      phase_layout="nhwc_cat")
+                outs.append(o.view(-1, 2))
+        return torch.cat(outs, 0)
+
+    def assemble(self, out_rows, plan, label_name=('valence', 'arousal')):
+        """[rows,2] -> {video index: float64 [n_frames,2]} with the reference's overwrite order."""
+        out_rows = out_rows.detach().cpu().numpy()
+        res = {}
+        for i, v in enumerate(plan["videos"]):
+            T = v["T"]
+            preds = [out_rows[v["row0"] + k * T: v["row0"] + (k + 1) * T] for k in range(len(v["ranges"]))]
+            res[i] = sampler.assemble(preds, v["ranges"], len(label_name))
+        return res

@@ -1,0 +1,79 @@
+"""Tester on MI355X -- the build's counterpart of api/tester.py:14-139.
+
+Same constructor keywords.  `test(video)` keeps the reference's directory contract
+(`<video>_opface/<video>_aligned/frame_det_00_%06d.bmp`, api/video_processor.py:69-84) but does NOT run
+OpenFace (external C++ face tracker, out of scope): the aligned-face directory must already exist -- the
+reference itself skips OpenFace when it does (api/video_processor.py:64-66).  `test_frames` takes in-memory
+aligned faces (what the bench uses).  Results: {video_name: DataFrame[valence, arousal]} like the reference.
+"""
+import os
+
+import numpy as np
+import torch
+
+from . import sampler, synthetic, weights
+from .phase_difference_extractor import phase_diff_output as _phase_diff_output
+from .pipeline import HotPath
+
+
+class Tester(object):
+    def __init__(self, model_path, batch_size, workers=0,
+                 save_size=112, nomask=True, grey=False, quiet=True, tracked_vid=False, noface_save=False,
+                 OpenFace_exe='OpenFace/build/bin/FeatureExtraction',
+                 benchmark_dir='pytorch-benchmarks', model_name='resnet50_ferplus_dag', feature_layer='pool5_7x7_s1',
+                 num_phase=12, phase_size=48, length=64, stride=64,
+                 height=4, nbands=2, scale_factor=2, extract_level=[1, 2],
+                 head_state_dict=None, resnet_state_dict=None, device=None):
+        if (num_phase, phase_size, height, nbands, scale_factor, list(extract_level)) != (12, 48, 4, 2, 2, [1, 2]):
+            raise NotImplementedError("only the published configuration (api/tester.py:28-32) is implemented")
+        self.batch_size, self.workers = batch_size, workers
+        self.num_phase, self.phase_size, self.length, self.stride = num_phase, phase_size, length, stride
+        self.label_name = ['valence', 'arousal']  # api/tester.py:52
+        if head_state_dict is None:
+            assert os.path.exists(model_path)  # api/tester.py:46
+            checkpoint = torch.load(model_path, map_location='cpu')
+            head_state_dict = checkpoint['state_dict']
+            print("load checkpoint from {}, epoch:{}".format(model_path, checkpoint['epoch']))
+        if resnet_state_dict is None:
+            pth = os.path.join(os.path.abspath(benchmark_dir), 'ferplus', model_name + '.pth')
+            assert os.path.exists(pth), 'benchmark_dir must exits'
+            resnet_state_dict = torch.load(pth, map_location='cpu')
+        self.hot = HotPath(head_state_dict, resnet_state_dict, device, length, stride, num_phase, batch_size)
+        self.device = self.hot.device
+        self.phase_difference_extractor = self.hot.pde
+        self.resnet50_extractor = self.hot.resnet
+        self.model = self.hot.head
+
+    # -- reference surface ---------------------------------------------------------------------------
+    def phase_diff_output(self, phase_batch, steerable_pyramid):
+        return _phase_diff_output(phase_batch, steerable_pyramid)
+
+    def test(self, input_video):
+        import pandas as pd
+        video_name = os.path.basename(input_video).split('.')[0]
+        opface_output_dir = os.path.join(os.path.dirname(input_video), video_name + "_opface")
+        if not os.path.isdir(os.path.join(opface_output_dir, video_name + "_aligned")):
+            raise RuntimeError("aligned faces not found under %s: run OpenFace FeatureExtraction first "
+                               "(api/video_processor.py:69-84); the face tracker is outside this build" % opface_output_dir)
+        frames = sampler.list_aligned_frames(opface_output_dir, video_name)
+        paths = [p for _, p in frames]
+        gray = sampler.load_gray_batch(paths, self.phase_size).to(self.device)
+        rgb = sampler.load_rgb_batch(paths).to(self.device)
+        res = self._run([len(paths)], gray, rgb)
+        return {video_name: pd.DataFrame(data=res[0], columns=self.label_name)}
+
+    def test_frames(self, clips_u8, names=None):
+        """clips_u8: list of uint8 arrays [n_i,112,112,3] (aligned faces).  -> {name: DataFrame}."""
+        import pandas as pd
+        grays, rgbs = zip(*[synthetic.preprocess_host(c, self.phase_size) for c in clips_u8])
+        gray = torch.from_numpy(np.concatenate(grays)).to(self.device)
+        rgb = torch.from_numpy(np.concatenate(rgbs)).to(self.device)
+        res = self._run([len(c) for c in clips_u8], gray, rgb)
+        names = names or ["clip%d" % i for i in range(len(clips_u8))]
+        return {names[i]: pd.DataFrame(data=res[i], columns=self.label_name) for i in range(len(clips_u8))}
+
+    def _run(self, lengths, gray, rgb):
+        plan = self.hot.plan(lengths)
+        with torch.no_grad():
+            out = self.hot.forward(gray, rgb, plan)
+        return self.hot.assemble(out, plan, self.label_name)
