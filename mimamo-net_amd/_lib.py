@@ -65,6 +65,10 @@ def lib():
             raise RuntimeError(
                 "libmimamo_hip.so is missing at %s -- build it with `python -c \"import __graft_entry__ as g; "
                 "g.build()\"` (hipcc --offload-arch=gfx950).  There is no CPU/PyTorch fallback." % LIB_PATH)
+        # PyTorch-ROCm bundles its own libamdhip64.so.7; import it FIRST so that this library binds to the same
+        # HIP runtime instance (same SONAME -> the loader reuses it).  Loading ours first would pull in
+        # /opt/rocm's runtime and leave torch on a mixed stack ("no device").
+        import torch  # noqa: F401
         l = ctypes.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(l, name)  # AttributeError if the .so does not export a declared symbol

@@ -22,6 +22,7 @@
 // Epilogue (fused): + bias (BN folded on the host) [+ residual] [ReLU] [* post_scale + post_shift]
 // (BN placed after ReLU, mimamo_net.py:54-62,115-117), stored as 128-byte channel rows.
 #include "mm_common.h"
+#include <cstdio>
 #include "conv.h"
 
 namespace mm {
@@ -83,6 +84,8 @@ conv_mfma_kernel(const ConvParams p) {
     }
 
     float4 ra[AIT], rb[BIT];
+    // Predication without branches: an out-of-image tap / k tail / row tail loads from a safe address
+    // (the tensor base) and is zeroed by a select, so all loads of a chunk issue back to back.
     auto gload = [&](int kc) {
         const int k0 = kc * CBK + kq * 4;
         const int rs = k0 / p.Cin, c = k0 - rs * p.Cin;
@@ -92,12 +95,15 @@ conv_mfma_kernel(const ConvParams p) {
         for (int it = 0; it < AIT; ++it) {
             const int hi = a_hi0[it] + r, wi = a_wi0[it] + s;
             const bool ok = kok && a_ok[it] && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
-            const float* src = p.in + a_base[it] + ((int64_t)hi * p.W + wi) * p.in_cstride + c;
-            ra[it] = ok ? *reinterpret_cast<const float4*>(src) : float4{0.f, 0.f, 0.f, 0.f};
+            const int64_t off = ok ? a_base[it] + ((int64_t)hi * p.W + wi) * p.in_cstride + c : 0;
+            const float4 v = *reinterpret_cast<const float4*>(p.in + off);
+            ra[it] = ok ? v : float4{0.f, 0.f, 0.f, 0.f};
         }
 #pragma unroll
-        for (int it = 0; it < BIT; ++it)
-            rb[it] = b_ok[it] ? *reinterpret_cast<const float4*>(b_ptr[it] + kc * CBK) : float4{0.f, 0.f, 0.f, 0.f};
+        for (int it = 0; it < BIT; ++it) {
+            const float4 v = *reinterpret_cast<const float4*>(b_ptr[it] + kc * CBK);
+            rb[it] = b_ok[it] ? v : float4{0.f, 0.f, 0.f, 0.f};
+        }
     };
     auto lstore = [&](int buf) {
 #pragma unroll
@@ -150,7 +156,64 @@ conv_mfma_kernel(const ConvParams p) {
         __syncthreads();
     }
 
-    // ---- fused epilogue.  C layout: col = lane & 31, row = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5)
+    // ---- fused epilogue.  MFMA C layout: col = lane & 31, row = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5), i.e. a
+    // lane owns a 16-row strip of ONE channel.  Per-lane stores of that layout are 4-byte, row-strided and
+    // issue-bound, so each wave transposes its tile through LDS (the operand buffers are dead) and every lane
+    // then owns 4 consecutive channels of a row: bias/residual/output all move as 16-byte, 256-byte-per-row
+    // coalesced accesses.
+    const bool wide = ((p.Cout | p.out_cstride | p.out_coff | p.res_cstride | p.res_coff) & 3) == 0;
+    if (wide) {
+        constexpr int SLD = WN + 4;                 // staging row stride (floats)
+        constexpr int QN = WN / 4;                  // float4 per staged row
+        constexpr int RPI = 64 / QN;                // rows covered by one wave-wide float4 access
+        float* st = lds + wave * (32 * SLD);        // 32 x WN per wave; 4 * 32 * SLD <= 2 * (BM + BN) * CLD
+        static_assert(4 * 32 * SLD <= 2 * (BM + BN) * CLD, "staging fits in the operand buffers");
+        const int qc = lane % QN, qr = lane / QN;
+        const int n0 = n_base + wn * WN + qc * 4;
+        const bool nok = n0 < p.Cout;
+        float4 bias4 = {0.f, 0.f, 0.f, 0.f}, ps4 = {1.f, 1.f, 1.f, 1.f}, pt4 = {0.f, 0.f, 0.f, 0.f};
+        if (nok && p.bias) bias4 = *reinterpret_cast<const float4*>(p.bias + n0);
+        if (nok && p.post_scale) {
+            ps4 = *reinterpret_cast<const float4*>(p.post_scale + n0);
+            pt4 = *reinterpret_cast<const float4*>(p.post_shift + n0);
+        }
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e)
+                    st[((e & 3) + 8 * (e >> 2) + 4 * lh) * SLD + j * 32 + lr] = acc[i][j][e];
+            __syncthreads();
+            const int m0 = m_base + wm * WM + i * 32;
+            float4 v[32 / RPI], rsd[32 / RPI];
+#pragma unroll
+            for (int t = 0; t < 32 / RPI; ++t) {
+                const int row = t * RPI + qr;
+                v[t] = *reinterpret_cast<const float4*>(st + row * SLD + qc * 4);
+                const int m = m0 + row;
+                if (p.res) {
+                    const int64_t mo = (nok && m < p.M) ? (int64_t)m * p.res_cstride + p.res_coff + n0 : 0;
+                    rsd[t] = *reinterpret_cast<const float4*>(p.res + mo);
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < 32 / RPI; ++t) {
+                const int m = m0 + t * RPI + qr;
+                float4 o = v[t];
+                o.x += bias4.x; o.y += bias4.y; o.z += bias4.z; o.w += bias4.w;
+                if (p.res) { o.x += rsd[t].x; o.y += rsd[t].y; o.z += rsd[t].z; o.w += rsd[t].w; }
+                if (p.relu) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
+                if (p.post_scale) {
+                    o.x = o.x * ps4.x + pt4.x; o.y = o.y * ps4.y + pt4.y; o.z = o.z * ps4.z + pt4.z; o.w = o.w * ps4.w + pt4.w;
+                }
+                if (nok && m < p.M) *reinterpret_cast<float4*>(p.out + (int64_t)m * p.out_cstride + p.out_coff + n0) = o;
+            }
+            if (i + 1 < TM) __syncthreads();
+        }
+        return;
+    }
+    // narrow fallback (channel counts / strides not multiples of 4, e.g. the 2-wide classifier)
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int n = n_base + wn * WN + j * 32 + lr;
@@ -181,7 +244,11 @@ static int launch_cfg(ConvParams p, hipStream_t stream) {
     p.tiles_n = (p.Cout + BN - 1) / BN;
     const int64_t blocks = (int64_t)p.tiles_m * p.tiles_n;
     if (blocks <= 0 || blocks > 0x7fffffff) return MM_ERR_INVALID_ARG;
-    prof_before(0, 2.0 * (double)p.M * (double)(p.kh * p.kw * p.Cin_real) * (double)p.Cout, stream);
+    if (prof_enabled()) {
+        char tag[64];
+        snprintf(tag, sizeof(tag), "M=%d K=%d N=%d k%d s%d t%dx%d", p.M, p.K, p.Cout, p.kh, p.stride, BM, BN);
+        prof_before(0, 2.0 * (double)p.M * (double)(p.kh * p.kw * p.Cin_real) * (double)p.Cout, stream, tag);
+    }
     hipLaunchKernelGGL((conv_mfma_kernel<BM, BN>), dim3((unsigned)blocks), dim3(256), 0, stream, p);
     prof_after(0, stream);
     MM_LAUNCH_CHECK();

@@ -28,7 +28,7 @@ inline int hip_fail(hipError_t e) {
 
 // ---- optional launch timing (profile.hip)
 bool prof_enabled();
-void prof_before(int cat, double work, hipStream_t s);
+void prof_before(int cat, double work, hipStream_t s, const char* tag = nullptr);
 void prof_after(int cat, hipStream_t s);
 
 // ---- host-side pyramid constants (mm_masks.cpp) -------------------------------------

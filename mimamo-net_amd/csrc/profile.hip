@@ -1,5 +1,7 @@
 // Optional in-library launch timing (bench.py's roofline leg): while enabled, every kernel launch of a
 // category is bracketed by hipEvents on the stream it is launched on.  Off by default; zero overhead then.
+#include <cstdio>
+#include <cstdlib>
 #include <mutex>
 #include "mm_common.h"
 
@@ -8,6 +10,7 @@ namespace mm {
 struct ProfRec {
     int cat;
     double work;
+    char tag[64];
     hipEvent_t e0, e1;
 };
 static bool g_prof_on = false;
@@ -16,11 +19,12 @@ static std::mutex g_prof_mu;
 
 bool prof_enabled() { return g_prof_on; }
 
-void prof_before(int cat, double work, hipStream_t s) {
+void prof_before(int cat, double work, hipStream_t s, const char* tag) {
     if (!g_prof_on) return;
     ProfRec r;
     r.cat = cat;
     r.work = work;
+    snprintf(r.tag, sizeof(r.tag), "%s", tag ? tag : "");
     if (hipEventCreate(&r.e0) != hipSuccess || hipEventCreate(&r.e1) != hipSuccess) return;
     (void)hipEventRecord(r.e0, s);
     std::lock_guard<std::mutex> g(g_prof_mu);
@@ -56,16 +60,20 @@ int mm_profile_end(double* ms, double* work, int64_t* launches) {
     MM_HIP(hipDeviceSynchronize());
     std::lock_guard<std::mutex> g(mm::g_prof_mu);
     for (int c = 0; c < MM_PROF_CATEGORIES; ++c) { ms[c] = 0; work[c] = 0; launches[c] = 0; }
+    const char* dump = getenv("MM_PROF_DUMP");  // optional per-launch CSV: cat,work,ms,tag
+    FILE* f = dump ? fopen(dump, "w") : nullptr;
     for (auto& r : mm::g_recs) {
         float t = 0.f;
         if (hipEventElapsedTime(&t, r.e0, r.e1) == hipSuccess && r.cat >= 0 && r.cat < MM_PROF_CATEGORIES) {
             ms[r.cat] += t;
             work[r.cat] += r.work;
             launches[r.cat] += 1;
+            if (f) fprintf(f, "%d,%.0f,%.5f,%s\n", r.cat, r.work, t, r.tag);
         }
         (void)hipEventDestroy(r.e0);
         (void)hipEventDestroy(r.e1);
     }
+    if (f) fclose(f);
     mm::g_recs.clear();
     return MM_OK;
 }
