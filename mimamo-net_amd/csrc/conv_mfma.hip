@@ -28,6 +28,7 @@
 namespace mm {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int CBK = 16;   // k-chunk
 constexpr int CLD = 20;   // LDS row stride (floats)
@@ -57,61 +58,87 @@ conv_mfma_kernel(const ConvParams p) {
     const int tile_m = logical / p.tiles_n, tile_n = logical - tile_m * p.tiles_n;
     const int m_base = tile_m * BM, n_base = tile_n * BN;
 
-    // ---- per-thread gather state: rows (tid>>2) + 64*it, k-quad (tid&3)
+    // ---- operand fetch through buffer descriptors: the hardware range check returns 0 for any offset
+    //      >= num_records, which gives zero padding (image border taps, K tail, row/channel tails) without
+    //      branches or selects on the data.  The A descriptor is rebased to the first image this block
+    //      touches so 32-bit byte offsets always suffice (a block spans a handful of images).
+    const int hw_out = p.Ho * p.Wo;
+    const int img0 = m_base / hw_out;                                  // wave-uniform
+    const int64_t img_elems = (int64_t)p.H * p.W * p.in_cstride;
+    const int64_t rem_elems = ((int64_t)p.B - img0) * img_elems;
+    const unsigned a_bytes = rem_elems * 4 > 0xFFFFF000ll ? 0xFFFFF000u : (unsigned)(rem_elems * 4);
+    const __amdgpu_buffer_rsrc_t rsrc_a =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.in) + img0 * img_elems, 0, a_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_b =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.w), 0, (unsigned)((int64_t)p.Cout * p.Kpad * 4), 0x00020000);
+    constexpr unsigned OOB = 0xFFFFFFFFu;
+
+    // per-thread rows (tid>>2) + 64*it and k-quad (tid&3)
     const int kq = tid & 3, lrow = tid >> 2;
-    int a_hi0[AIT], a_wi0[AIT];
-    int64_t a_base[AIT];
+    int a_hi0[AIT], a_wi0[AIT], a_pix[AIT];
     bool a_ok[AIT];
 #pragma unroll
     for (int it = 0; it < AIT; ++it) {
         const int m = m_base + lrow + it * 64;
         a_ok[it] = m < p.M;
-        const int mm_ = a_ok[it] ? m : 0;
-        const int hw = p.Ho * p.Wo;
-        const int b = mm_ / hw, rem = mm_ - b * hw;
+        const int mm_ = a_ok[it] ? m : m_base;
+        const int b = mm_ / hw_out, rem = mm_ - b * hw_out;
         const int ho = rem / p.Wo, wo = rem - ho * p.Wo;
         a_hi0[it] = ho * p.stride - p.pad;
         a_wi0[it] = wo * p.stride - p.pad;
-        a_base[it] = (int64_t)b * p.H * p.W * p.in_cstride + p.in_coff;
+        // element offset of tap (0,0), channel 0, relative to the descriptor base (may be negative: padding)
+        a_pix[it] = (b - img0) * (int)img_elems + (a_hi0[it] * p.W + a_wi0[it]) * p.in_cstride + p.in_coff;
     }
-    const float* b_ptr[BIT];
-    bool b_ok[BIT];
+    unsigned vb[BIT];
 #pragma unroll
     for (int it = 0; it < BIT; ++it) {
         const int n = n_base + lrow + it * 64;
-        b_ok[it] = n < p.Cout;
-        b_ptr[it] = p.w + (int64_t)(b_ok[it] ? n : 0) * p.Kpad + kq * 4;
+        vb[it] = n < p.Cout ? (unsigned)(n * p.Kpad + kq * 4) * 4u : OOB;
     }
-
-    float4 ra[AIT], rb[BIT];
-    // Predication without branches: an out-of-image tap / k tail / row tail loads from a safe address
-    // (the tensor base) and is zeroed by a select, so all loads of a chunk issue back to back.
-    auto gload = [&](int kc) {
-        const int k0 = kc * CBK + kq * 4;
-        const int rs = k0 / p.Cin, c = k0 - rs * p.Cin;
-        const int r = rs / p.kw, s = rs - r * p.kw;
-        const bool kok = k0 < p.K;
+    // tap state of this lane's k-quad: k = (r*kw + s)*Cin + c, advanced by one chunk (16) per iteration
+    int tk = kq * 4, tr, ts, tc;
+    {
+        const int rs = tk / p.Cin;
+        tc = tk - rs * p.Cin;
+        tr = rs / p.kw;
+        ts = rs - tr * p.kw;
+    }
+    unsigned va[AIT];
+    auto tap_offsets = [&]() {
+        const int tapoff = (tr * p.W + ts) * p.in_cstride + tc;
+        const bool kok = tk < p.K;
 #pragma unroll
         for (int it = 0; it < AIT; ++it) {
-            const int hi = a_hi0[it] + r, wi = a_wi0[it] + s;
+            const int hi = a_hi0[it] + tr, wi = a_wi0[it] + ts;
             const bool ok = kok && a_ok[it] && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
-            const int64_t off = ok ? a_base[it] + ((int64_t)hi * p.W + wi) * p.in_cstride + c : 0;
-            const float4 v = *reinterpret_cast<const float4*>(p.in + off);
-            ra[it] = ok ? v : float4{0.f, 0.f, 0.f, 0.f};
+            va[it] = ok ? (unsigned)(a_pix[it] + tapoff) * 4u : OOB;
+        }
+    };
+    auto tap_advance = [&]() {
+        tk += CBK;
+        tc += CBK;
+        while (tc >= p.Cin) {
+            tc -= p.Cin;
+            if (++ts == p.kw) { ts = 0; ++tr; }
         }
 #pragma unroll
-        for (int it = 0; it < BIT; ++it) {
-            const float4 v = *reinterpret_cast<const float4*>(b_ptr[it] + kc * CBK);
-            rb[it] = b_ok[it] ? v : float4{0.f, 0.f, 0.f, 0.f};
-        }
+        for (int it = 0; it < BIT; ++it) vb[it] = vb[it] == OOB ? OOB : vb[it] + CBK * 4u;
+    };
+
+    u32x4 ga[AIT], gb[BIT];
+    auto gload = [&]() {
+#pragma unroll
+        for (int it = 0; it < AIT; ++it) ga[it] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_a, va[it], 0, 0);
+#pragma unroll
+        for (int it = 0; it < BIT; ++it) gb[it] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_b, vb[it], 0, 0);
     };
     auto lstore = [&](int buf) {
 #pragma unroll
         for (int it = 0; it < AIT; ++it)
-            *reinterpret_cast<float4*>(As + (buf * BM + lrow + it * 64) * CLD + kq * 4) = ra[it];
+            *reinterpret_cast<u32x4*>(As + (buf * BM + lrow + it * 64) * CLD + kq * 4) = ga[it];
 #pragma unroll
         for (int it = 0; it < BIT; ++it)
-            *reinterpret_cast<float4*>(Bs + (buf * BN + lrow + it * 64) * CLD + kq * 4) = rb[it];
+            *reinterpret_cast<u32x4*>(Bs + (buf * BN + lrow + it * 64) * CLD + kq * 4) = gb[it];
     };
 
     f32x16 acc[TM][TN];
@@ -124,35 +151,47 @@ conv_mfma_kernel(const ConvParams p) {
 
     const int lr = lane & 31, lh = lane >> 5;
     const int nk = p.Kpad / CBK;
-    gload(0);
+    // One barrier per 16-deep chunk.  Iteration kc: fragments of chunk kc LDS->registers, loads of chunk kc+1
+    // issued with offsets computed one iteration earlier (no VALU in front of them), offsets of chunk kc+2
+    // computed in the shadow of the 32 MFMAs, then chunk kc+1 registers->LDS (other buffer) and the barrier.
+    // Loads/stores past the last chunk are harmless (range check -> zeros into a buffer nobody reads).
+    tap_offsets();
+    gload();
+    tap_advance();
+    tap_offsets();
     lstore(0);
     __syncthreads();
     for (int kc = 0; kc < nk; ++kc) {
         const int buf = kc & 1;
-        if (kc + 1 < nk) gload(kc + 1);
-        float af[TM][8], bf[TN][8];
+        float4 fa[TM][2], fb[TN][2];
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
-            const float4* s = reinterpret_cast<const float4*>(As + (buf * BM + wm * WM + i * 32 + lr) * CLD + lh * 8);
-            const float4 v0 = s[0], v1 = s[1];
-            af[i][0] = v0.x; af[i][1] = v0.y; af[i][2] = v0.z; af[i][3] = v0.w;
-            af[i][4] = v1.x; af[i][5] = v1.y; af[i][6] = v1.z; af[i][7] = v1.w;
+            const float4* q = reinterpret_cast<const float4*>(As + (buf * BM + wm * WM + i * 32 + lr) * CLD + lh * 8);
+            fa[i][0] = q[0];
+            fa[i][1] = q[1];
         }
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
-            const float4* s = reinterpret_cast<const float4*>(Bs + (buf * BN + wn * WN + j * 32 + lr) * CLD + lh * 8);
-            const float4 v0 = s[0], v1 = s[1];
-            bf[j][0] = v0.x; bf[j][1] = v0.y; bf[j][2] = v0.z; bf[j][3] = v0.w;
-            bf[j][4] = v1.x; bf[j][5] = v1.y; bf[j][6] = v1.z; bf[j][7] = v1.w;
+            const float4* q = reinterpret_cast<const float4*>(Bs + (buf * BN + wn * WN + j * 32 + lr) * CLD + lh * 8);
+            fb[j][0] = q[0];
+            fb[j][1] = q[1];
         }
+        gload();
+        tap_advance();
+        tap_offsets();
 #pragma unroll
-        for (int kk = 0; kk < 8; ++kk)
+        for (int h = 0; h < 2; ++h)
 #pragma unroll
-            for (int i = 0; i < TM; ++i)
+            for (int kk = 0; kk < 4; ++kk)
 #pragma unroll
-                for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][kk], bf[j][kk], acc[i][j], 0, 0, 0);
-        if (kc + 1 < nk) lstore(buf ^ 1);
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) {
+                        const float a = kk == 0 ? fa[i][h].x : kk == 1 ? fa[i][h].y : kk == 2 ? fa[i][h].z : fa[i][h].w;
+                        const float b = kk == 0 ? fb[j][h].x : kk == 1 ? fb[j][h].y : kk == 2 ? fb[j][h].z : fb[j][h].w;
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[i][j], 0, 0, 0);
+                    }
+        lstore(buf ^ 1);
         __syncthreads();
     }
 
@@ -258,6 +297,13 @@ static int launch_cfg(ConvParams p, hipStream_t stream) {
 int conv_forward(const ConvParams& p0, hipStream_t stream) {
     ConvParams p = p0;
     if (p.Cin % 4 || p.in_cstride % 4 || p.in_coff % 4 || p.Kpad % CBK || p.K > p.Kpad) return MM_ERR_INVALID_ARG;
+    // 32-bit byte offsets inside the kernel: the weight matrix, and the few images one 128-row block spans
+    if ((uint64_t)p.Cout * p.Kpad * 4 >= 0xFFFFF000ull) return MM_ERR_INVALID_ARG;
+    {
+        const int64_t hw_o = (int64_t)p.Ho * p.Wo;
+        const int64_t span = 128 / (hw_o > 0 ? hw_o : 1) + 2;
+        if (span * p.H * p.W * p.in_cstride * 4 >= 0x7FFFF000ll) return MM_ERR_INVALID_ARG;
+    }
     p.M = p.B * p.Ho * p.Wo;
     if (p.M <= 0) return MM_OK;
     if (p.Cin_real <= 0) p.Cin_real = p.Cin;
