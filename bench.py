@@ -6,7 +6,7 @@ Workload at N=1 (BASELINE configs[3]): a batch of independent 64-frame clips, fu
 (steerable pyramid + phase difference, ResNet50 pool5, PhaseNet/MLP/GRU head), fp32, random-init weights of
 the reference architecture, synthetic 112x112 aligned-face clips preprocessed to the tensors the reference's
 hot path consumes (gray 48x48 in [0,1]; RGB 224x224 = 255x-mean), resident in HBM before the timed region.
-One step = one pass of the hot path over `--clips` clips (default 16 -> 1024 frames) per GPU.
+One step = one pass of the hot path over `--clips` clips (default 32 -> 2048 frames) per GPU.
 
 N>1: one process per GPU (torch.distributed, backend nccl = RCCL), clips sharded across ranks (weak scaling,
 `--clips` per rank), no data-path collective; per-clip results are all-gathered (8 B/frame) inside the timed
@@ -76,7 +76,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--clips", type=int, default=16, help="64-frame clips per GPU per step")
+    ap.add_argument("--clips", type=int, default=32, help="64-frame clips per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=64)
     args = ap.parse_args()

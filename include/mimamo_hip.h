@@ -117,16 +117,18 @@ typedef struct mm_head mm_head_t;
 /* The conv engine itself (one launch): NHWC fp32 convolution / linear layer with fused epilogue
  *   out = [post_scale *] relu?( conv(in, w) + bias [+ residual] ) [+ post_shift]
  * in  [B,H,W,in_cstride]  channels [in_coff, in_coff+Cin) are read   (Cin, in_cstride, in_coff multiples of 4)
- * w   [Cout][Kpad] packed weights, k = (r*kw + s)*Cin + c, Kpad = K rounded up to 16, zero filled
+ * w   [Cout][Kpad] packed weights, Kpad = K rounded up to 16, zero filled;
+ *     korder 0: k = (r*kw + s)*Cin + c;  korder 1 (Cin % 16 == 0): k = ((c/16*kh + r)*kw + s)*16 + c%16
+ *     (slice-major: the taps of a 16-channel slice are adjacent, which keeps the kh*kw-fold input re-use in L2)
  * out [B,Ho,Wo,out_cstride] channels [out_coff, out_coff+Cout) are written; residual [B,Ho,Wo,res_cstride].
- * bias/residual/post_scale/post_shift may be NULL.  tile: 0 auto, 1 = 128x128, 2 = 128x64, 3 = 64x64.
+ * bias/residual/post_scale/post_shift may be NULL.  tile: 0 auto, 1 = 128x128, 2 = 128x64, 3 = 64x64, 4 = 256x64.
  * This is what torch.nn.functional.conv2d / linear + BatchNorm(eval) + ReLU lower to on this path
  * (api/mimamo_net.py:14-26,68-78; the third-party ResNet50's conv/bn/relu triples). */
 int mm_conv2d_nhwc(const float* in, const float* w, const float* bias, const float* residual,
                    const float* post_scale, const float* post_shift, float* out,
                    int B, int H, int W, int Cin, int in_cstride, int in_coff,
                    int Cout, int out_cstride, int out_coff, int res_cstride,
-                   int kh, int kw, int stride, int pad, int relu, int tile, void* stream);
+                   int kh, int kw, int stride, int pad, int relu, int tile, int korder, void* stream);
 
 /* Weight blob: host f32 array, tensors concatenated in the order of mm_resnet50_blob_floats /
  * documented in mimamo-net_amd/weights.py (per conv: weight OIHW, then BN gamma, beta,

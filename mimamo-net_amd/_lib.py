@@ -32,7 +32,7 @@ SIGNATURES = {
     "mm_phase_diff_frames": (_i, [_vp, _vp, _i64, _vp, _i64, _vp, _i, _i, _i, _vp, _i, _i, _i, _vp, _i64, _vp]),
     "mm_profile_begin": (_i, []),
     "mm_profile_end": (_i, [_c.POINTER(_c.c_double), _c.POINTER(_c.c_double), _c.POINTER(_c.c_int64)]),
-    "mm_conv2d_nhwc": (_i, [_vp] * 7 + [_i] * 16 + [_vp]),
+    "mm_conv2d_nhwc": (_i, [_vp] * 7 + [_i] * 17 + [_vp]),
     "mm_resnet50_blob_floats": (_i64, []),
     "mm_resnet50_create": (_i, [_c.POINTER(_vp), _vp, _i64, _i, _i, _f]),
     "mm_resnet50_destroy": (_i, [_vp]),

@@ -17,8 +17,10 @@ struct ConvParams {
     int res_cstride, res_coff;
     int kh, kw, stride, pad;
     int K, Kpad;
+    int korder;      // 0: k=(r,s,c)   1: k=(c/16,r,s,c%16), needs Cin % 16 == 0 (see conv_mfma.hip)
     int relu;
-    int force_tile;  // 0 auto, 1 = 128x128, 2 = 128x64, 3 = 64x64
+    int force_tile;  // 0 auto, 1 = 128x128, 2 = 128x64, 3 = 64x64, 4 = 256x64, 16+bits = ablation build (measurement only)
+    int ablate;
     int Cin_real;    // un-padded input channels (FLOP accounting only; 0 = Cin)
     int M, tiles_m, tiles_n;  // filled by conv_forward
 };

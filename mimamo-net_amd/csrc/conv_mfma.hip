@@ -33,10 +33,13 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 constexpr int CBK = 16;   // k-chunk
 constexpr int CLD = 20;   // LDS row stride (floats)
 
-template <int BM, int BN>
+// ABL: measurement-only instantiation whose loop stages can be switched off at run time (p.ablate bits:
+// 1 no global loads, 2 no LDS stores, 4 no barrier, 8 no fragment reads) to attribute time; results are wrong.
+template <int BM, int BN, int WGM, int WGN, bool ABL = false>
 __global__ void __launch_bounds__(256)
 conv_mfma_kernel(const ConvParams p) {
-    constexpr int WM = BM / 2, WN = BN / 2;
+    static_assert(WGM * WGN == 4, "four waves per workgroup");
+    constexpr int WM = BM / WGM, WN = BN / WGN;
     constexpr int TM = WM / 32, TN = WN / 32;
     constexpr int AIT = BM / 64, BIT = BN / 64;
     __shared__ __attribute__((aligned(16))) float lds[2 * (BM + BN) * CLD];
@@ -44,7 +47,7 @@ conv_mfma_kernel(const ConvParams p) {
     float* Bs = lds + 2 * BM * CLD;       // [2][BN][CLD]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / WGN, wn = wave % WGN;
 
     // XCD-aware tile order: workgroup b runs on XCD b % 8; give each XCD a contiguous run of logical
     // tiles, n-tiles of one m-tile adjacent, so the activation rows they share stay in that XCD's L2.
@@ -95,13 +98,22 @@ conv_mfma_kernel(const ConvParams p) {
         const int n = n_base + lrow + it * 64;
         vb[it] = n < p.Cout ? (unsigned)(n * p.Kpad + kq * 4) * 4u : OOB;
     }
-    // tap state of this lane's k-quad: k = (r*kw + s)*Cin + c, advanced by one chunk (16) per iteration
+    // tap state of this lane's k-quad, advanced by one chunk (16) per iteration.  Two K orders:
+    //   korder 0:  k = (r*kw + s)*Cin + c              (any Cin % 4 == 0)
+    //   korder 1:  k = ((c/16 * kh + r)*kw + s)*16 + c%16   (Cin % 16 == 0): all taps of a 16-channel slice are
+    //              consecutive chunks, so the ~kh*kw-fold re-use of every input pixel happens within a few
+    //              chunks and is served by L1/L2 instead of the fabric (measured: conv4_x 3x3 fetched 8.5x its
+    //              input with korder 0).
     int tk = kq * 4, tr, ts, tc;
-    {
+    if (p.korder == 0) {
         const int rs = tk / p.Cin;
         tc = tk - rs * p.Cin;
         tr = rs / p.kw;
         ts = rs - tr * p.kw;
+    } else {
+        tc = tk;  // chunk 0 = slice 0, tap (0,0)
+        tr = 0;
+        ts = 0;
     }
     unsigned va[AIT];
     auto tap_offsets = [&]() {
@@ -116,10 +128,15 @@ conv_mfma_kernel(const ConvParams p) {
     };
     auto tap_advance = [&]() {
         tk += CBK;
-        tc += CBK;
-        while (tc >= p.Cin) {
-            tc -= p.Cin;
-            if (++ts == p.kw) { ts = 0; ++tr; }
+        if (p.korder == 0) {
+            tc += CBK;
+            while (tc >= p.Cin) {
+                tc -= p.Cin;
+                if (++ts == p.kw) { ts = 0; ++tr; }
+            }
+        } else if (++ts == p.kw) {
+            ts = 0;
+            if (++tr == p.kh) { tr = 0; tc += CBK; }
         }
 #pragma unroll
         for (int it = 0; it < BIT; ++it) vb[it] = vb[it] == OOB ? OOB : vb[it] + CBK * 4u;
@@ -161,24 +178,34 @@ conv_mfma_kernel(const ConvParams p) {
     tap_offsets();
     lstore(0);
     __syncthreads();
+    float4 fa[TM][2], fb[TN][2];
+    if (ABL) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) fa[i][0] = fa[i][1] = float4{1.f, 2.f, 3.f, 4.f};
+#pragma unroll
+        for (int j = 0; j < TN; ++j) fb[j][0] = fb[j][1] = float4{1.f, 2.f, 3.f, 4.f};
+    }
     for (int kc = 0; kc < nk; ++kc) {
         const int buf = kc & 1;
-        float4 fa[TM][2], fb[TN][2];
+        if (!ABL || !(p.ablate & 8)) {
 #pragma unroll
-        for (int i = 0; i < TM; ++i) {
-            const float4* q = reinterpret_cast<const float4*>(As + (buf * BM + wm * WM + i * 32 + lr) * CLD + lh * 8);
-            fa[i][0] = q[0];
-            fa[i][1] = q[1];
-        }
+            for (int i = 0; i < TM; ++i) {
+                const float4* q = reinterpret_cast<const float4*>(As + (buf * BM + wm * WM + i * 32 + lr) * CLD + lh * 8);
+                fa[i][0] = q[0];
+                fa[i][1] = q[1];
+            }
 #pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const float4* q = reinterpret_cast<const float4*>(Bs + (buf * BN + wn * WN + j * 32 + lr) * CLD + lh * 8);
-            fb[j][0] = q[0];
-            fb[j][1] = q[1];
+            for (int j = 0; j < TN; ++j) {
+                const float4* q = reinterpret_cast<const float4*>(Bs + (buf * BN + wn * WN + j * 32 + lr) * CLD + lh * 8);
+                fb[j][0] = q[0];
+                fb[j][1] = q[1];
+            }
         }
-        gload();
-        tap_advance();
-        tap_offsets();
+        if (!ABL || !(p.ablate & 1)) {
+            gload();
+            tap_advance();
+            tap_offsets();
+        }
 #pragma unroll
         for (int h = 0; h < 2; ++h)
 #pragma unroll
@@ -191,8 +218,8 @@ conv_mfma_kernel(const ConvParams p) {
                         const float b = kk == 0 ? fb[j][h].x : kk == 1 ? fb[j][h].y : kk == 2 ? fb[j][h].z : fb[j][h].w;
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[i][j], 0, 0, 0);
                     }
-        lstore(buf ^ 1);
-        __syncthreads();
+        if (!ABL || !(p.ablate & 2)) lstore(buf ^ 1);
+        if (!ABL || !(p.ablate & 4)) __syncthreads();
     }
 
     // ---- fused epilogue.  MFMA C layout: col = lane & 31, row = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5), i.e. a
@@ -277,7 +304,7 @@ conv_mfma_kernel(const ConvParams p) {
     }
 }
 
-template <int BM, int BN>
+template <int BM, int BN, int WGM, int WGN, bool ABL = false>
 static int launch_cfg(ConvParams p, hipStream_t stream) {
     p.tiles_m = (p.M + BM - 1) / BM;
     p.tiles_n = (p.Cout + BN - 1) / BN;
@@ -288,7 +315,7 @@ static int launch_cfg(ConvParams p, hipStream_t stream) {
         snprintf(tag, sizeof(tag), "M=%d K=%d N=%d k%d s%d t%dx%d", p.M, p.K, p.Cout, p.kh, p.stride, BM, BN);
         prof_before(0, 2.0 * (double)p.M * (double)(p.kh * p.kw * p.Cin_real) * (double)p.Cout, stream, tag);
     }
-    hipLaunchKernelGGL((conv_mfma_kernel<BM, BN>), dim3((unsigned)blocks), dim3(256), 0, stream, p);
+    hipLaunchKernelGGL((conv_mfma_kernel<BM, BN, WGM, WGN, ABL>), dim3((unsigned)blocks), dim3(256), 0, stream, p);
     prof_after(0, stream);
     MM_LAUNCH_CHECK();
     return MM_OK;
@@ -297,6 +324,7 @@ static int launch_cfg(ConvParams p, hipStream_t stream) {
 int conv_forward(const ConvParams& p0, hipStream_t stream) {
     ConvParams p = p0;
     if (p.Cin % 4 || p.in_cstride % 4 || p.in_coff % 4 || p.Kpad % CBK || p.K > p.Kpad) return MM_ERR_INVALID_ARG;
+    if (p.korder != 0 && (p.korder != 1 || p.Cin % CBK)) return MM_ERR_INVALID_ARG;
     // 32-bit byte offsets inside the kernel: the weight matrix, and the few images one 128-row block spans
     if ((uint64_t)p.Cout * p.Kpad * 4 >= 0xFFFFF000ull) return MM_ERR_INVALID_ARG;
     {
@@ -307,12 +335,29 @@ int conv_forward(const ConvParams& p0, hipStream_t stream) {
     p.M = p.B * p.Ho * p.Wo;
     if (p.M <= 0) return MM_OK;
     if (p.Cin_real <= 0) p.Cin_real = p.Cin;
-    // tile choice: the largest tile that still gives every CU (256) a couple of workgroups
-    const int64_t t128 = (int64_t)((p.M + 127) / 128) * ((p.Cout + 127) / 128);
-    if (p.force_tile == 1 || (p.force_tile == 0 && p.Cout > 64 && t128 >= 512)) return launch_cfg<128, 128>(p, stream);
-    const int64_t t12864 = (int64_t)((p.M + 127) / 128) * ((p.Cout + 63) / 64);
-    if (p.force_tile == 2 || (p.force_tile == 0 && t12864 >= 512)) return launch_cfg<128, 64>(p, stream);
-    return launch_cfg<64, 64>(p, stream);
+    // Tile choice.  Wave tile 64x64 (2x2 MFMA sub-tiles, 4 accumulators) is the efficient shape: 128x128
+    // blocks (2x2 waves) when Cout > 64, 256x64 blocks (4x1 waves) for the 64-channel layers; smaller tiles
+    // only when the grid would not give every CU (256) a couple of workgroups.
+    const int64_t m128 = (p.M + 127) / 128, m256 = (p.M + 255) / 256;
+    const int64_t n128 = (p.Cout + 127) / 128, n64 = (p.Cout + 63) / 64;
+    int cfg = p.force_tile;
+    if (cfg >= 16) {  // measurement-only: 128x128 with ablation bits (cfg - 16)
+        p.ablate = cfg - 16;
+        return launch_cfg<128, 128, 2, 2, true>(p, stream);
+    }
+    if (cfg == 0) {
+        if (p.Cout > 64 && m128 * n128 >= 512) cfg = 1;
+        else if (p.Cout <= 64 && m256 * n64 >= 512) cfg = 4;
+        else if (m128 * n64 >= 512) cfg = 2;
+        else cfg = 3;
+    }
+    switch (cfg) {
+        case 1: return launch_cfg<128, 128, 2, 2>(p, stream);
+        case 2: return launch_cfg<128, 64, 2, 2>(p, stream);
+        case 3: return launch_cfg<64, 64, 2, 2>(p, stream);
+        case 4: return launch_cfg<256, 64, 4, 1>(p, stream);
+        default: return MM_ERR_INVALID_ARG;
+    }
 }
 
 }  // namespace mm

@@ -22,9 +22,27 @@ nchw_to_nhwc_kernel(const float* __restrict__ in, float* __restrict__ out, int C
     }
 }
 
+// 3-channel planes -> channels-last padded to 4 (the ResNet input): three coalesced plane reads, one float4 store
+__global__ void __launch_bounds__(256)
+nchw3_to_nhwc4_kernel(const float* __restrict__ in, float4* __restrict__ out, int64_t total, int HW) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int64_t n = i / HW;
+    const int hw = (int)(i - n * HW);
+    const float* p = in + n * 3 * HW + hw;
+    out[i] = float4{p[0], p[HW], p[2 * (int64_t)HW], 0.f};
+}
+
 int nchw_to_nhwc(const float* in, float* out, int64_t N, int C, int HW, int cstride, int coff, int cpad, hipStream_t s) {
     if (N <= 0) return MM_OK;
     if (cpad < C) cpad = C;
+    if (C == 3 && cpad == 4 && cstride == 4 && coff == 0) {
+        const int64_t total = N * HW;
+        hipLaunchKernelGGL(nchw3_to_nhwc4_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, in,
+                           reinterpret_cast<float4*>(out), total, HW);
+        MM_LAUNCH_CHECK();
+        return MM_OK;
+    }
     dim3 grid((HW + 31) / 32, (cpad + 31) / 32, (unsigned)N);
     hipLaunchKernelGGL(nchw_to_nhwc_kernel, grid, dim3(256), 0, s, in, out, C, HW, cstride, coff, cpad);
     MM_LAUNCH_CHECK();

@@ -17,7 +17,7 @@ namespace mm {
 
 struct Layer {
     float *w = nullptr, *bias = nullptr, *ps = nullptr, *pt = nullptr;
-    int cin = 0, cin_p = 0, cout = 0, k = 1, stride = 1, pad = 0, K = 0, Kpad = 0, relu = 0;
+    int cin = 0, cin_p = 0, cout = 0, k = 1, stride = 1, pad = 0, K = 0, Kpad = 0, relu = 0, korder = 0;
 };
 
 struct DeviceArena {
@@ -55,6 +55,7 @@ static int make_layer(DeviceArena& A, Layer& L, const float* w, const float* bia
     L.relu = relu;
     L.K = k * k * L.cin_p;
     L.Kpad = (L.K + 15) / 16 * 16;
+    L.korder = (k > 1 && L.cin_p % 16 == 0) ? 1 : 0;  // slice-major K: taps of a 16-channel slice adjacent
     std::vector<float> hw((size_t)cout * L.Kpad, 0.f), hb(cout, 0.f);
     for (int o = 0; o < cout; ++o) {
         double sc = 1.0, sh = 0.0;
@@ -65,8 +66,11 @@ static int make_layer(DeviceArena& A, Layer& L, const float* w, const float* bia
         for (int c = 0; c < cin; ++c)
             for (int r = 0; r < k; ++r)
                 for (int s = 0; s < k; ++s)
-                    hw[(size_t)o * L.Kpad + (size_t)(r * k + s) * L.cin_p + c] =
-                        (float)((double)w[(((size_t)o * cin + c) * k + r) * k + s] * sc);
+                {
+                    const size_t kidx = L.korder == 0 ? (size_t)(r * k + s) * L.cin_p + c
+                                                      : ((size_t)((c / 16) * k + r) * k + s) * 16 + c % 16;
+                    hw[(size_t)o * L.Kpad + kidx] = (float)((double)w[(((size_t)o * cin + c) * k + r) * k + s] * sc);
+                }
         hb[o] = (float)((bias ? (double)bias[o] : 0.0) * sc + sh);
     }
     int rc = A.upload(hw, &L.w);
@@ -96,7 +100,7 @@ static int run_layer(const Layer& L, const float* in, int B, int H, int W, int i
     p.Cout = L.cout; p.out_cstride = out_cstride; p.out_coff = out_coff;
     p.res_cstride = res_cstride; p.res_coff = 0;
     p.kh = L.k; p.kw = L.k; p.stride = L.stride; p.pad = L.pad;
-    p.K = L.K; p.Kpad = L.Kpad; p.relu = L.relu; p.Cin_real = L.cin;
+    p.K = L.K; p.Kpad = L.Kpad; p.relu = L.relu; p.Cin_real = L.cin; p.korder = L.korder;
     if (Ho_) *Ho_ = p.Ho;
     if (Wo_) *Wo_ = p.Wo;
     return conv_forward(p, s);
@@ -179,10 +183,10 @@ extern "C" {
 int mm_conv2d_nhwc(const float* in, const float* w, const float* bias, const float* residual, const float* post_scale,
                    const float* post_shift, float* out, int B, int H, int W, int Cin, int in_cstride, int in_coff,
                    int Cout, int out_cstride, int out_coff, int res_cstride, int kh, int kw, int stride, int pad,
-                   int relu, int tile, void* stream) {
+                   int relu, int tile, int korder, void* stream) {
     using namespace mm;
     if (!in || !w || !out || B < 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || kh <= 0 || kw <= 0 || stride <= 0 ||
-        pad < 0 || tile < 0 || tile > 3)
+        pad < 0 || tile < 0 || tile > 31)
         return MM_ERR_INVALID_ARG;
     if ((post_scale == nullptr) != (post_shift == nullptr)) return MM_ERR_INVALID_ARG;
     ConvParams p;
@@ -194,7 +198,7 @@ int mm_conv2d_nhwc(const float* in, const float* w, const float* bias, const flo
     if (p.Ho <= 0 || p.Wo <= 0 || (int64_t)B * p.Ho * p.Wo > 0x7fffffff) return MM_ERR_INVALID_ARG;
     p.Cout = Cout; p.out_cstride = out_cstride; p.out_coff = out_coff; p.res_cstride = res_cstride;
     p.kh = kh; p.kw = kw; p.stride = stride; p.pad = pad;
-    p.K = kh * kw * Cin; p.Kpad = (p.K + 15) / 16 * 16; p.relu = relu; p.force_tile = tile;
+    p.K = kh * kw * Cin; p.Kpad = (p.K + 15) / 16 * 16; p.relu = relu; p.force_tile = tile; p.korder = korder;
     return conv_forward(p, (hipStream_t)stream);
 }
 

@@ -21,13 +21,16 @@ def dev():
     return torch.device("cuda:0")
 
 
-def _pack(w):
-    """OIHW -> [Cout][Kpad], k = (r*kw+s)*Cin + c."""
+def _pack(w, korder=0):
+    """OIHW -> [Cout][Kpad]; korder 0: k = (r*kw+s)*Cin + c, korder 1: k = ((c/16*kh + r)*kw + s)*16 + c%16."""
     co, ci, kh, kw = w.shape
     k = kh * kw * ci
     kp = (k + 15) // 16 * 16
     out = np.zeros((co, kp), dtype=np.float32)
-    out[:, :k] = w.transpose(0, 2, 3, 1).reshape(co, k)
+    if korder == 0:
+        out[:, :k] = w.transpose(0, 2, 3, 1).reshape(co, k)
+    else:
+        out[:, :k] = w.reshape(co, ci // 16, 16, kh, kw).transpose(0, 1, 3, 4, 2).reshape(co, k)
     return out
 
 
@@ -41,13 +44,18 @@ CASES = [
     (5, 1, 1, 2048, 256, 1, 1, 0, 1, 0),     # Linear
     (4, 28, 28, 128, 128, 3, 1, 1, 1, 1),    # 128x128 tiles, several m tiles
     (2, 12, 12, 88, 128, 3, 1, 1, 1, 2),     # K = 792
+    (3, 20, 20, 64, 64, 3, 1, 1, 1, 4),      # 256x64 tiles (4x1 waves), M = 1200: ragged last tile
+    (1, 23, 23, 4, 64, 7, 2, 3, 1, 4),       # stem-like on 256x64
 ]
 
 
+@pytest.mark.parametrize("korder", [0, 1])
 @pytest.mark.parametrize("case", CASES)
-def test_conv_engine_vs_torch(pkg, dev, case):
+def test_conv_engine_vs_torch(pkg, dev, case, korder):
     from mimamo_net_amd import _lib
     B, H, W, Ci, Co, k, st, pad, relu, tile = case
+    if korder == 1 and Ci % 16:
+        pytest.skip("slice-major K order needs Cin % 16 == 0")
     x = weights.det_uniform("cx", (B, Ci, H, W), -1, 1, 1)
     w = weights.det_uniform("cw", (Co, Ci, k, k), -1, 1, 2) / np.sqrt(Ci * k * k).astype(np.float32)
     b = weights.det_uniform("cb", (Co,), -0.5, 0.5, 3)
@@ -66,9 +74,9 @@ def test_conv_engine_vs_torch(pkg, dev, case):
     xin = xin.to(dev)
     out = torch.full((B, Ho, Wo, Co + 5), -7.0, device=dev)
     t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
-    wd, bd, rd, psd, ptd = t(_pack(w)), t(b), t(res.transpose(0, 2, 3, 1)), t(ps), t(pt)
+    wd, bd, rd, psd, ptd = t(_pack(w, korder)), t(b), t(res.transpose(0, 2, 3, 1)), t(ps), t(pt)
     rc = _lib.lib().mm_conv2d_nhwc(_lib.ptr(xin), _lib.ptr(wd), _lib.ptr(bd), _lib.ptr(rd), _lib.ptr(psd), _lib.ptr(ptd),
-                                   _lib.ptr(out), B, H, W, Ci, Ci + 8, 4, Co, Co + 5, 5, Co, k, k, st, pad, relu, tile,
+                                   _lib.ptr(out), B, H, W, Ci, Ci + 8, 4, Co, Co + 5, 5, Co, k, k, st, pad, relu, tile, korder,
                                    _lib.current_stream())
     assert rc == 0
     got = out.cpu().numpy()

@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Micro-benchmark of the conv/GEMM engine through the C ABI (mm_conv2d_nhwc) on one shape.
-usage: conv_bench.py B H W Cin Cout k stride pad [tile] [iters] [res]"""
+usage: conv_bench.py B H W Cin Cout k stride pad [tile] [iters] [res] [korder]"""
 import os
 import sys
 import time
@@ -11,7 +11,7 @@ import mimamo_net_amd  # noqa: E402,F401
 from mimamo_net_amd import _lib  # noqa: E402
 
 
-def run(B, H, W, Ci, Co, k, st, pad, tile=0, iters=20, res=0, relu=1):
+def run(B, H, W, Ci, Co, k, st, pad, tile=0, iters=20, res=0, korder=0, relu=1):
     dev = torch.device("cuda:0")
     Ho, Wo = (H + 2 * pad - k) // st + 1, (W + 2 * pad - k) // st + 1
     K = k * k * Ci
@@ -25,7 +25,7 @@ def run(B, H, W, Ci, Co, k, st, pad, tile=0, iters=20, res=0, relu=1):
 
     def go():
         rc = L.mm_conv2d_nhwc(_lib.ptr(x), _lib.ptr(w), _lib.ptr(b), _lib.ptr(r), None, None, _lib.ptr(out),
-                              B, H, W, Ci, Ci, 0, Co, Co, 0, Co, k, k, st, pad, relu, tile, _lib.current_stream())
+                              B, H, W, Ci, Ci, 0, Co, Co, 0, Co, k, k, st, pad, relu, tile, korder, _lib.current_stream())
         assert rc == 0, rc
     for _ in range(3):
         go()
@@ -38,8 +38,8 @@ def run(B, H, W, Ci, Co, k, st, pad, tile=0, iters=20, res=0, relu=1):
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / iters
     fl = 2.0 * B * Ho * Wo * K * Co
-    print("B%d %dx%d Cin%d Cout%d k%d s%d tile%d res%d: M=%d K=%d  %.3f ms  %.1f TFLOP/s" %
-          (B, H, W, Ci, Co, k, st, tile, res, B * Ho * Wo, K, ms, fl / ms / 1e9))
+    print("B%d %dx%d Cin%d Cout%d k%d s%d tile%d res%d korder%d: M=%d K=%d  %.3f ms  %.1f TFLOP/s" %
+          (B, H, W, Ci, Co, k, st, tile, res, korder, B * Ho * Wo, K, ms, fl / ms / 1e9))
     return ms
 
 
@@ -49,9 +49,10 @@ if __name__ == "__main__":
         run(*a)
     else:
         run(1, 64, 64, 4096, 4096, 1, 1, 0, 1)       # 4096^3 GEMM
-        run(512, 14, 14, 256, 256, 3, 1, 1, 1)       # ResNet conv4_x 3x3
-        run(512, 28, 28, 128, 128, 3, 1, 1, 1)       # conv3_x 3x3
-        run(512, 7, 7, 512, 512, 3, 1, 1, 1)         # conv5_x 3x3
-        run(512, 56, 56, 64, 64, 3, 1, 1, 2)         # conv2_x 3x3
+        for ko in (0, 1):
+            run(512, 14, 14, 256, 256, 3, 1, 1, 1, 20, 0, ko)       # ResNet conv4_x 3x3
+            run(512, 28, 28, 128, 128, 3, 1, 1, 1, 20, 0, ko)       # conv3_x 3x3
+            run(512, 7, 7, 512, 512, 3, 1, 1, 1, 20, 0, ko)         # conv5_x 3x3
+            run(512, 56, 56, 64, 64, 3, 1, 1, 2, 20, 0, ko)         # conv2_x 3x3
         run(512, 14, 14, 1024, 256, 1, 1, 0, 1)
         run(512, 14, 14, 256, 1024, 1, 1, 0, 1, 20, 1)
