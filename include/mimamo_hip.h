@@ -165,6 +165,27 @@ int mm_head_forward(mm_head_t* h, const float* phase_0, const float* phase_1, in
                     void* workspace, int64_t workspace_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------------------
+ * Frame preprocessing, bit-exact with the PIL pipeline of the reference's DataLoader workers
+ * replaces: Image.open(bmp).convert('L') + GroupScale(48, LANCZOS) + /255
+ *             (api/sampler/snippet_sampler.py:163,177-185; api/utils/data_utils.py:80)
+ *           Resize(256, bilinear) + CenterCrop(224) + ToTensor + x*255 + Normalize(mean, std=1)
+ *             (api/utils/model_utils.py:29-39; api/sampler/image_sampler.py)
+ * ------------------------------------------------------------------------------------- */
+typedef struct mm_preproc mm_preproc_t;
+/* Host-side table builder exposed for testing (no GPU): Pillow's fixed-point resampling coefficients for a full-axis
+ * resize in_size -> out_size; filter 0 = bilinear, 1 = lanczos.  Call with bounds = kk = NULL to query *ksize;
+ * bounds [out_size][2] = {first input index, count}, kk [out_size][ksize] (22 fractional bits). */
+int mm_preproc_host_coeffs(int in_size, int out_size, int filter, int* ksize, int* bounds, int* kk, int kk_capacity);
+/* in_size: side of the aligned-face frames (112); gray_size 48; resize 256; crop 224; mean3: meta['mean']. */
+int mm_preproc_create(mm_preproc_t** out, int in_size, int gray_size, int resize, int crop, const float* mean3);
+int mm_preproc_destroy(mm_preproc_t* h);
+/* frames: device uint8 [n, in_size, in_size, 3] (RGB, the BMP pixel order).  gray_out: f32 [n,gray,gray] in [0,1];
+ * rgb_out: f32 [n,3,crop,crop] (rgb_nchw=1) or channels-last padded [n,crop,crop,4] (rgb_nchw=0), 255*x - mean.
+ * Either output may be NULL. */
+int mm_preproc_forward(mm_preproc_t* h, const uint8_t* frames, int64_t n, float* gray_out, float* rgb_out,
+                       int rgb_nchw, void* stream);
+
+/* ---------------------------------------------------------------------------------------
  * Measurement hook (bench.py roofline leg; not part of the reference surface).  Between begin and
  * end every kernel launch is bracketed by hipEvents on its own stream.  Categories: 0 conv/GEMM
  * engine (work = algorithmic FLOPs 2*M*K*Cout), 1 pyramid kernel, 2 phase-window kernel (work =

@@ -30,6 +30,10 @@ SIGNATURES = {
     "mm_phase_extract": (_i, [_vp, _vp, _vp, _i64, _i64, _i64, _i, _i, _vp, _i, _i, _i, _vp]),
     "mm_phase_workspace_bytes": (_i64, [_vp, _i64]),
     "mm_phase_diff_frames": (_i, [_vp, _vp, _i64, _vp, _i64, _vp, _i, _i, _i, _vp, _i, _i, _i, _vp, _i64, _vp]),
+    "mm_preproc_host_coeffs": (_i, [_i, _i, _i, _c.POINTER(_i), _c.POINTER(_i), _c.POINTER(_i), _i]),
+    "mm_preproc_create": (_i, [_c.POINTER(_vp), _i, _i, _i, _i, _c.POINTER(_f)]),
+    "mm_preproc_destroy": (_i, [_vp]),
+    "mm_preproc_forward": (_i, [_vp, _vp, _i64, _vp, _vp, _i, _vp]),
     "mm_profile_begin": (_i, []),
     "mm_profile_end": (_i, [_c.POINTER(_c.c_double), _c.POINTER(_c.c_double), _c.POINTER(_c.c_int64)]),
     "mm_conv2d_nhwc": (_i, [_vp] * 7 + [_i] * 17 + [_vp]),

@@ -1,0 +1,269 @@
+// Frame preprocessing on the GPU, bit-exact with the PIL pipeline the reference runs in DataLoader workers
+// (SURVEY.md 8f-1):
+//   gray : Image.open(bmp).convert('L') -> GroupScale(48, Image.LANCZOS) -> /255
+//          (api/sampler/snippet_sampler.py:163,177-185; api/utils/data_utils.py:80)
+//   rgb  : Resize(256) [PIL bilinear] -> CenterCrop(224) -> ToTensor -> x*255 -> Normalize(mean, 1)
+//          (api/utils/model_utils.py:29-39; api/sampler/image_sampler.py)
+// PIL resamples 8-bit images in fixed point (Pillow src/libImaging/Resample.c): per axis a table of
+// double-precision filter weights normalised to sum 1, converted to integers with 22 fractional bits
+// (round half away from zero), a horizontal pass then a vertical pass, each accumulating
+// 2^21 + sum(u8 * coeff) in int32 and storing clip8(acc >> 22) -- i.e. the intermediate image is uint8.
+// The tables are rebuilt here on the host with the same formulas; the kernels are pure integer work
+// followed by the reference's fp32 epilogue evaluated with explicitly un-fused IEEE operations.
+#include <cmath>
+#include <new>
+#include <vector>
+#include "mm_common.h"
+
+namespace mm {
+
+constexpr int PRECISION_BITS = 32 - 8 - 2;
+
+struct ResampleTable {
+    int in_size = 0, out_size = 0, ksize = 0;
+    std::vector<int> bounds;  // [out][2]: xmin, count
+    std::vector<int> kk;      // [out][ksize]
+};
+
+static double sinc_filter(double x) {
+    if (x == 0.0) return 1.0;
+    x = x * 3.14159265358979323846;
+    return std::sin(x) / x;
+}
+static double lanczos_filter(double x) { return (-3.0 <= x && x < 3.0) ? sinc_filter(x) * sinc_filter(x / 3) : 0.0; }
+static double bilinear_filter(double x) {
+    if (x < 0.0) x = -x;
+    return x < 1.0 ? 1.0 - x : 0.0;
+}
+
+// Pillow precompute_coeffs + normalize_coeffs_8bpc for a full-axis resize (box = whole image).
+// filter: 0 = bilinear (support 1), 1 = lanczos (support 3)
+int build_resample_table(int in_size, int out_size, int filter, ResampleTable& t) {
+    if (in_size <= 0 || out_size <= 0 || filter < 0 || filter > 1) return MM_ERR_INVALID_ARG;
+    double (*f)(double) = filter == 0 ? bilinear_filter : lanczos_filter;
+    const double fsupport = filter == 0 ? 1.0 : 3.0;
+    double filterscale, scale;
+    filterscale = scale = (double)in_size / out_size;
+    if (filterscale < 1.0) filterscale = 1.0;
+    const double support = fsupport * filterscale;
+    const int ksize = (int)std::ceil(support) * 2 + 1;
+    t.in_size = in_size;
+    t.out_size = out_size;
+    t.ksize = ksize;
+    t.bounds.assign((size_t)out_size * 2, 0);
+    t.kk.assign((size_t)out_size * ksize, 0);
+    std::vector<double> k(ksize);
+    for (int xx = 0; xx < out_size; ++xx) {
+        const double center = 0.0 + (xx + 0.5) * scale;
+        double ww = 0.0;
+        const double ss = 1.0 / filterscale;
+        int xmin = (int)(center - support + 0.5);
+        if (xmin < 0) xmin = 0;
+        int xmax = (int)(center + support + 0.5);
+        if (xmax > in_size) xmax = in_size;
+        xmax -= xmin;
+        int x = 0;
+        for (; x < xmax; ++x) {
+            const double w = f((x + xmin - center + 0.5) * ss);
+            k[x] = w;
+            ww += w;
+        }
+        for (x = 0; x < xmax; ++x)
+            if (ww != 0.0) k[x] /= ww;
+        for (; x < ksize; ++x) k[x] = 0;
+        t.bounds[xx * 2] = xmin;
+        t.bounds[xx * 2 + 1] = xmax;
+        for (x = 0; x < ksize; ++x) {
+            const double v = k[x] * (double)(1 << PRECISION_BITS);
+            t.kk[(size_t)xx * ksize + x] = k[x] < 0 ? (int)(-0.5 + v) : (int)(0.5 + v);
+        }
+    }
+    return MM_OK;
+}
+
+__device__ __forceinline__ int clip8(int acc) {
+    const int v = acc >> PRECISION_BITS;
+    return v < 0 ? 0 : (v > 255 ? 255 : v);
+}
+
+// ---- gray: one workgroup per frame ------------------------------------------------------------------
+// LDS: L plane [S][S] u8, horizontal-pass image [S][G] u8.
+__global__ void __launch_bounds__(256)
+preproc_gray_kernel(const uint8_t* __restrict__ frames, int S, int G, int ksize, const int* __restrict__ bounds,
+                    const int* __restrict__ kk, float* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* L = smem;            // [S*S]
+    unsigned char* T = smem + S * S;    // [S*G]
+    const int64_t n = blockIdx.x;
+    const uint8_t* src = frames + n * (int64_t)S * S * 3;
+    const int tid = threadIdx.x;
+    // convert('L'): (19595 R + 38470 G + 7471 B + 0x8000) >> 16
+    for (int i = tid; i < S * S; i += 256) {
+        const unsigned r = src[i * 3], g = src[i * 3 + 1], b = src[i * 3 + 2];
+        L[i] = (unsigned char)((19595u * r + 38470u * g + 7471u * b + 0x8000u) >> 16);
+    }
+    __syncthreads();
+    for (int i = tid; i < S * G; i += 256) {  // horizontal pass
+        const int y = i / G, xx = i - y * G;
+        const int xmin = bounds[xx * 2], cnt = bounds[xx * 2 + 1];
+        const int* k = kk + xx * ksize;
+        int acc = 1 << (PRECISION_BITS - 1);
+        for (int x = 0; x < cnt; ++x) acc += (int)L[y * S + xmin + x] * k[x];
+        T[i] = (unsigned char)clip8(acc);
+    }
+    __syncthreads();
+    for (int i = tid; i < G * G; i += 256) {  // vertical pass + /255
+        const int yy = i / G, xx = i - yy * G;
+        const int ymin = bounds[yy * 2], cnt = bounds[yy * 2 + 1];
+        const int* k = kk + yy * ksize;
+        int acc = 1 << (PRECISION_BITS - 1);
+        for (int y = 0; y < cnt; ++y) acc += (int)T[(ymin + y) * G + xx] * k[y];
+        out[n * (int64_t)G * G + i] = __fdiv_rn((float)clip8(acc), 255.0f);
+    }
+}
+
+// ---- rgb: bilinear S -> R, centre crop C, normalise.  grid (frames, row tiles of 16 output rows) -------
+__global__ void __launch_bounds__(256)
+preproc_rgb_kernel(const uint8_t* __restrict__ frames, int S, int R, int C, int ksize, const int* __restrict__ bounds,
+                   const int* __restrict__ kk, float mean0, float mean1, float mean2, float* __restrict__ out, int nchw) {
+    const int64_t n = blockIdx.x;
+    const int row0 = blockIdx.y * 16;
+    const int off = (int)rintf((R - C) / 2.0f);  // CenterCrop: int(round((256-224)/2.)) = 16
+    const uint8_t* src = frames + n * (int64_t)S * S * 3;
+    const float mean[3] = {mean0, mean1, mean2};
+    for (int i = threadIdx.x; i < 16 * C; i += 256) {
+        const int ry = i / C, cx = i - ry * C;
+        const int oy = row0 + ry;
+        if (oy >= C) break;
+        const int yy = oy + off, xx = cx + off;                 // position in the R x R resized image
+        const int ymin = bounds[yy * 2], ycnt = bounds[yy * 2 + 1];
+        const int xmin = bounds[xx * 2], xcnt = bounds[xx * 2 + 1];
+        const int* ky = kk + yy * ksize;
+        const int* kx = kk + xx * ksize;
+        int accv[3] = {1 << (PRECISION_BITS - 1), 1 << (PRECISION_BITS - 1), 1 << (PRECISION_BITS - 1)};
+        for (int y = 0; y < ycnt; ++y) {
+            // horizontal pass value of input row (ymin + y) at column xx: uint8 after clip8, as PIL stores it
+            int acch[3] = {1 << (PRECISION_BITS - 1), 1 << (PRECISION_BITS - 1), 1 << (PRECISION_BITS - 1)};
+            const uint8_t* rowp = src + ((int64_t)(ymin + y) * S + xmin) * 3;
+            for (int x = 0; x < xcnt; ++x) {
+                const int w = kx[x];
+                acch[0] += (int)rowp[x * 3] * w;
+                acch[1] += (int)rowp[x * 3 + 1] * w;
+                acch[2] += (int)rowp[x * 3 + 2] * w;
+            }
+            const int w = ky[y];
+            accv[0] += clip8(acch[0]) * w;
+            accv[1] += clip8(acch[1]) * w;
+            accv[2] += clip8(acch[2]) * w;
+        }
+        float v[3];
+        {
+            // ToTensor (/255), *255.0, -mean are three separately rounded fp32 operations in the reference; HIP's
+            // default -ffp-contract=fast would fuse the last two into one FMA (1-ulp differences), so contraction
+            // is switched off for this block.
+#pragma clang fp contract(off)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const float q = (float)clip8(accv[c]) / 255.0f;
+                const float m255 = q * 255.0f;
+                v[c] = m255 - mean[c];
+            }
+        }
+        if (nchw) {
+            float* o = out + n * 3 * (int64_t)C * C + (int64_t)oy * C + cx;
+            o[0] = v[0];
+            o[(int64_t)C * C] = v[1];
+            o[2 * (int64_t)C * C] = v[2];
+        } else {
+            reinterpret_cast<float4*>(out)[(n * C + oy) * (int64_t)C + cx] = float4{v[0], v[1], v[2], 0.f};
+        }
+    }
+}
+
+}  // namespace mm
+
+struct mm_preproc {
+    int in_size, gray_size, resize, crop;
+    float mean[3];
+    mm::ResampleTable lan, bil;
+    int *d_lan_bounds = nullptr, *d_lan_kk = nullptr, *d_bil_bounds = nullptr, *d_bil_kk = nullptr;
+};
+
+extern "C" {
+
+int mm_preproc_host_coeffs(int in_size, int out_size, int filter, int* ksize, int* bounds, int* kk, int kk_capacity) {
+    if (!ksize) return MM_ERR_INVALID_ARG;
+    mm::ResampleTable t;
+    int rc = mm::build_resample_table(in_size, out_size, filter, t);
+    if (rc != MM_OK) return rc;
+    *ksize = t.ksize;
+    if (bounds && kk) {
+        if (kk_capacity < (int)t.kk.size()) return MM_ERR_WORKSPACE;
+        for (size_t i = 0; i < t.bounds.size(); ++i) bounds[i] = t.bounds[i];
+        for (size_t i = 0; i < t.kk.size(); ++i) kk[i] = t.kk[i];
+    }
+    return MM_OK;
+}
+
+int mm_preproc_create(mm_preproc_t** out, int in_size, int gray_size, int resize, int crop, const float* mean3) {
+    if (!out) return MM_ERR_INVALID_ARG;
+    *out = nullptr;
+    if (in_size <= 0 || gray_size <= 0 || resize < crop || crop <= 0 || !mean3 || in_size * in_size + in_size * gray_size > 160 * 1024)
+        return MM_ERR_INVALID_ARG;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return MM_ERR_NO_DEVICE;
+    mm_preproc* h = new (std::nothrow) mm_preproc();
+    if (!h) return MM_ERR_INVALID_ARG;
+    h->in_size = in_size; h->gray_size = gray_size; h->resize = resize; h->crop = crop;
+    for (int c = 0; c < 3; ++c) h->mean[c] = mean3[c];
+    int rc = mm::build_resample_table(in_size, gray_size, 1, h->lan);
+    if (rc == MM_OK) rc = mm::build_resample_table(in_size, resize, 0, h->bil);
+    auto up = [&](const std::vector<int>& v, int** d) -> int {
+        MM_HIP(hipMalloc((void**)d, v.size() * sizeof(int)));
+        MM_HIP(hipMemcpy(*d, v.data(), v.size() * sizeof(int), hipMemcpyHostToDevice));
+        return MM_OK;
+    };
+    if (rc == MM_OK) rc = up(h->lan.bounds, &h->d_lan_bounds);
+    if (rc == MM_OK) rc = up(h->lan.kk, &h->d_lan_kk);
+    if (rc == MM_OK) rc = up(h->bil.bounds, &h->d_bil_bounds);
+    if (rc == MM_OK) rc = up(h->bil.kk, &h->d_bil_kk);
+    if (rc != MM_OK) {
+        mm_preproc_destroy(h);
+        return rc;
+    }
+    *out = h;
+    return MM_OK;
+}
+
+int mm_preproc_destroy(mm_preproc_t* h) {
+    if (!h) return MM_OK;
+    for (int* p : {h->d_lan_bounds, h->d_lan_kk, h->d_bil_bounds, h->d_bil_kk})
+        if (p) (void)hipFree(p);
+    delete h;
+    return MM_OK;
+}
+
+int mm_preproc_forward(mm_preproc_t* h, const uint8_t* frames, int64_t n, float* gray_out, float* rgb_out, int rgb_nchw,
+                       void* stream_) {
+    if (!h || n < 0 || (n > 0 && !frames) || (!gray_out && !rgb_out)) return MM_ERR_INVALID_ARG;
+    if (n == 0) return MM_OK;
+    hipStream_t s = (hipStream_t)stream_;
+    if (gray_out) {
+        const int lds = h->in_size * h->in_size + h->in_size * h->gray_size;
+        if (lds > 64 * 1024)
+            MM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(mm::preproc_gray_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        hipLaunchKernelGGL(mm::preproc_gray_kernel, dim3((unsigned)n), dim3(256), lds, s, frames, h->in_size, h->gray_size,
+                           h->lan.ksize, h->d_lan_bounds, h->d_lan_kk, gray_out);
+        MM_LAUNCH_CHECK();
+    }
+    if (rgb_out) {
+        dim3 grid((unsigned)n, (unsigned)((h->crop + 15) / 16));
+        hipLaunchKernelGGL(mm::preproc_rgb_kernel, grid, dim3(256), 0, s, frames, h->in_size, h->resize, h->crop, h->bil.ksize,
+                           h->d_bil_bounds, h->d_bil_kk, h->mean[0], h->mean[1], h->mean[2], rgb_out, rgb_nchw);
+        MM_LAUNCH_CHECK();
+    }
+    return MM_OK;
+}
+
+}  // extern "C"

@@ -65,10 +65,11 @@ class Tester(object):
     def test_frames(self, clips_u8, names=None):
         """clips_u8: list of uint8 arrays [n_i,112,112,3] (aligned faces).  -> {name: DataFrame}."""
         import pandas as pd
-        grays, rgbs = zip(*[synthetic.preprocess_host(c, self.phase_size) for c in clips_u8])
-        gray = torch.from_numpy(np.concatenate(grays)).to(self.device)
-        rgb = torch.from_numpy(np.concatenate(rgbs)).to(self.device)
-        res = self._run([len(c) for c in clips_u8], gray, rgb)
+        frames = torch.from_numpy(np.ascontiguousarray(np.concatenate(clips_u8))).to(self.device)
+        plan = self.hot.plan([len(c) for c in clips_u8])
+        with torch.no_grad():
+            out = self.hot.forward_u8(frames, plan)  # PIL-exact preprocessing on the GPU
+        res = self.hot.assemble(out, plan, self.label_name)
         names = names or ["clip%d" % i for i in range(len(clips_u8))]
         return {names[i]: pd.DataFrame(data=res[i], columns=self.label_name) for i in range(len(clips_u8))}
 

@@ -1,0 +1,80 @@
+"""GPU parity of the whole per-video path (Tester / HotPath) against the oracle driven with the reference's
+semantics: windowed 13x-redundant pyramid, ResNet50 features per frame, one GRU call per video with its snippets
+in sampler order (recurrence over snippets), tail-snippet overwrite."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from mimamo_net_amd import synthetic, weights, sampler
+
+pytestmark = pytest.mark.gpu
+OUT_ATOL = 1e-4
+
+
+@pytest.fixture(scope="module")
+def tester(pkg):
+    from mimamo_net_amd.tester import Tester
+    return Tester(model_path=None, batch_size=64, head_state_dict=weights.make_two_stream_state_dict(seed=0),
+                  resnet_state_dict=weights.make_resnet50_state_dict(seed=0), device="cuda:0")
+
+
+def _oracle_video(oracle, clip_u8, length=64, stride=64, batch_size=64):
+    gray, rgb = synthetic.preprocess_host(clip_u8)
+    n = len(clip_u8)
+    ranges = oracle.snippet_ranges(n, length, stride)
+    feats = oracle.resnet50_pool5(weights.make_resnet50_state_dict(seed=0), rgb)
+    sd = weights.make_two_stream_state_dict(seed=0)
+    T = ranges[0][1] - ranges[0][0]
+    ph = np.stack([gray[oracle.window_ids(s, e, n)] for s, e in ranges])      # [S,T,13,48,48]
+    rg = np.stack([feats[s:e] for s, e in ranges])                             # [S,T,2048]
+    preds = []
+    for c0 in range(0, len(ranges), batch_size):
+        p0, p1 = oracle.phase_diff_output(ph[c0:c0 + batch_size])
+        preds.extend(list(oracle.two_stream_forward(sd, p0, p1, rg[c0:c0 + batch_size])))
+    return oracle.assemble(preds, ranges)
+
+
+def test_multi_snippet_video_and_short_video(tester, oracle):
+    """150 frames -> snippets [0,64) [64,128) [86,150): GRU seq_len 3 + overwrite order; 20 frames -> short-video rule."""
+    clips = [synthetic.make_clip_u8(40, 150), synthetic.make_clip_u8(41, 20)]
+    res = tester.test_frames(clips, names=["a", "b"])
+    assert list(res["a"].columns) == ["valence", "arousal"] and res["a"].shape == (150, 2) and res["b"].shape == (20, 2)
+    for name, clip in zip(("a", "b"), clips):
+        want = _oracle_video(oracle, clip)
+        err = np.abs(res[name].values - want).max()
+        assert err < OUT_ATOL, (name, err)
+
+
+def test_independent_clip_batching_is_exact(tester):
+    """Batching single-snippet clips into one GRU call (seq_len 1) gives the same bits as one call per clip."""
+    clips = [synthetic.make_clip_u8(50 + i, 64) for i in range(3)]
+    frames = torch.from_numpy(np.concatenate(clips)).to(tester.device)
+    plan = tester.hot.plan([64, 64, 64])
+    with torch.no_grad():
+        a = tester.hot.forward_u8(frames, plan, independent_clips=True)
+        b = tester.hot.forward_u8(frames, plan, independent_clips=False)
+    assert torch.equal(a, b)
+
+
+def test_tester_reads_reference_directory_layout(tester, oracle, tmp_path):
+    """<video>_opface/<video>_aligned/frame_det_00_%06d.bmp (api/video_processor.py:69-84) + %05d.npy features."""
+    from PIL import Image
+    clip = synthetic.make_clip_u8(60, 12)
+    vid = tmp_path / "utt.mp4"
+    al = tmp_path / "utt_opface" / "utt_aligned"
+    os.makedirs(al)
+    for i, f in enumerate(clip):
+        Image.fromarray(f, "RGB").save(str(al / ("frame_det_00_%06d.bmp" % (i + 1))))
+    res = tester.test(str(vid))
+    assert list(res) == ["utt"] and res["utt"].shape == (12, 2)
+    want = _oracle_video(oracle, clip)
+    assert np.abs(res["utt"].values - want).max() < OUT_ATOL
+    # Resnet50_Extractor.run writes one %05d.npy per frame and skips when they exist (api/resnet50_extractor.py:61-72)
+    out_dir = tmp_path / "utt_pool5"
+    tester.resnet50_extractor.run(str(tmp_path / "utt_opface"), str(out_dir), video_name="utt")
+    files = sorted(os.listdir(out_dir))
+    assert files[0] == "00001.npy" and len(files) == 12 and np.load(str(out_dir / files[0])).shape == (2048,)
+    with pytest.raises(RuntimeError, match="aligned faces not found"):
+        tester.test(str(tmp_path / "missing.mp4"))

@@ -1,0 +1,76 @@
+"""Frame preprocessing: the library's fixed-point resampling tables + integer passes must be
+BIT-EXACT with PIL (the reference's transforms are PIL calls).  CPU part: host tables + a numpy emulation of the
+two passes vs PIL itself.  GPU part: the HIP kernels vs PIL on synthetic clips."""
+import ctypes
+
+import numpy as np
+import pytest
+
+from mimamo_net_amd import synthetic, weights
+
+
+def _tables(L, n_in, n_out, filt):
+    ks = ctypes.c_int()
+    assert L.mm_preproc_host_coeffs(n_in, n_out, filt, ctypes.byref(ks), None, None, 0) == 0
+    bounds = (ctypes.c_int * (n_out * 2))()
+    kk = (ctypes.c_int * (n_out * ks.value))()
+    assert L.mm_preproc_host_coeffs(n_in, n_out, filt, ctypes.byref(ks), bounds, kk, n_out * ks.value) == 0
+    return np.array(bounds).reshape(n_out, 2), np.array(kk).reshape(n_out, ks.value)
+
+
+def _resample_axis(img, bounds, kk, axis):
+    """One PIL pass: out = clip8((2^21 + sum u8*k) >> 22) along `axis` (uint8 in, uint8 out)."""
+    img = np.moveaxis(img.astype(np.int64), axis, 0)
+    out = np.empty((bounds.shape[0],) + img.shape[1:], dtype=np.int64)
+    for o, (lo, cnt) in enumerate(bounds):
+        acc = (1 << 21) + np.tensordot(kk[o, :cnt].astype(np.int64), img[lo:lo + cnt], axes=(0, 0))
+        out[o] = np.clip(acc >> 22, 0, 255)
+    return np.moveaxis(out, 0, axis).astype(np.uint8)
+
+
+@pytest.fixture(scope="module")
+def L(pkg):
+    from mimamo_net_amd import build, _lib
+    build.build_library()
+    return _lib.lib()
+
+
+def test_host_tables_emulation_is_bit_exact_with_pil(L):
+    from PIL import Image
+    clip = synthetic.make_clip_u8(9, 3)
+    noise = (weights.det_uniform("pp.noise", (2, 112, 112, 3), 0, 256, 3)).astype(np.uint8)  # full-range, hits clipping
+    frames = np.concatenate([clip, noise])
+    lb, lk = _tables(L, 112, 48, 1)
+    bb, bk = _tables(L, 112, 256, 0)
+    assert lk.shape[1] == 15 and bk.shape[1] == 3
+    for f in frames:
+        im = Image.fromarray(f, "RGB")
+        g = np.asarray(im.convert("L"))
+        np.testing.assert_array_equal(synthetic.to_gray_u8(f), g)
+        want = np.asarray(im.convert("L").resize((48, 48), Image.LANCZOS))
+        got = _resample_axis(_resample_axis(g, lb, lk, 1), lb, lk, 0)
+        np.testing.assert_array_equal(got, want)
+        want = np.asarray(im.resize((256, 256), Image.BILINEAR))
+        got = _resample_axis(_resample_axis(f, bb, bk, 1), bb, bk, 0)
+        np.testing.assert_array_equal(got, want)
+
+
+@pytest.mark.gpu
+def test_gpu_preprocessing_bit_exact_with_pil(pkg):
+    import torch
+    from mimamo_net_amd.preprocess import FramePreprocessor
+    dev = torch.device("cuda:0")
+    clip = synthetic.make_clip_u8(4, 6)
+    noise = (weights.det_uniform("pp.noise", (3, 112, 112, 3), 0, 256, 8)).astype(np.uint8)
+    frames = np.concatenate([clip, noise])
+    gray_ref, rgb_ref = synthetic.preprocess_host(frames)      # PIL, reference-style
+    pp = FramePreprocessor(device=dev)
+    g, r4 = pp(torch.from_numpy(frames).to(dev))
+    np.testing.assert_array_equal(g.cpu().numpy(), gray_ref)
+    r4 = r4.cpu().numpy()
+    np.testing.assert_array_equal(r4[..., :3].transpose(0, 3, 1, 2), rgb_ref)
+    assert (r4[..., 3] == 0).all()
+    _, r = pp(torch.from_numpy(frames).to(dev), channels_last4=False, want_gray=False)
+    np.testing.assert_array_equal(r.cpu().numpy(), rgb_ref)
+    with pytest.raises(RuntimeError):
+        pp(torch.from_numpy(frames))
