@@ -13,12 +13,12 @@
 // GEMM view:  out[m][n] = sum_k A[m][k] * Wt[n][k],  m = (b, ho, wo),  n = cout,  k = (r, s, c)
 //   activations NHWC (channel stride/offset allow channel-sliced reads and concat-writes),
 //   weights packed [Cout][Kpad] with k contiguous (Kpad = K rounded up to 16, zero filled).
-// Workgroup = 256 threads = 2x2 waves; block tile BM x BN x 16; each wave owns (BM/2)x(BN/2) as
-// 32x32 MFMA sub-tiles.  Both operand tiles are staged [row][16+4] in LDS: the +4 pad makes the
-// ds_read_b128 fragment reads and the global->LDS float4 writes bank-conflict free.  Inside a
-// 16-deep chunk lanes 0-31 take k = 0..7 and lanes 32-63 take k = 8..15 (any k order is a valid
-// contraction order), so one b128 read feeds four MFMAs.  Global loads for chunk i+1 are issued
-// before the MFMAs of chunk i (register prefetch, double-buffered LDS, one barrier per chunk).
+// Workgroup = 256 threads = 4 waves (2x2, or 4x1 for the 256x64 tile); block tile BM x BN x 16; each wave
+// owns (BM/WGM)x(BN/WGN) as 32x32 MFMA sub-tiles.  Operand tiles go global -> LDS directly
+// (buffer_load ... lds, no VGPR staging, no ds_write), double buffered, one barrier per 16-deep chunk;
+// the 16-byte slots of each LDS row are XOR-swizzled so the ds_read_b128 fragment reads are
+// bank-conflict free without padding.  Inside a chunk lanes 0-31 take k = 0..7 and lanes 32-63 take
+// k = 8..15 (any k order is a valid contraction order), so one b128 read feeds four MFMAs.
 // Epilogue (fused): + bias (BN folded on the host) [+ residual] [ReLU] [* post_scale + post_shift]
 // (BN placed after ReLU, mimamo_net.py:54-62,115-117), stored as 128-byte channel rows.
 #include "mm_common.h"
@@ -31,20 +31,31 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int CBK = 16;   // k-chunk
-constexpr int CLD = 20;   // LDS row stride (floats)
+constexpr int CLD = 16;   // LDS row = one 16-float chunk; the four 16-byte slots of a row are XOR-swizzled
 
 // ABL: measurement-only instantiation whose loop stages can be switched off at run time (p.ablate bits:
 // 1 no global loads, 2 no LDS stores, 4 no barrier, 8 no fragment reads) to attribute time; results are wrong.
-template <int BM, int BN, int WGM, int WGN, bool ABL = false>
+// KMODE selects the tap iteration at compile time (straight-line VALU in the hot loop):
+//   0  k = (r,s,c), any Cin % 4 == 0 (stem: Cin = 4)      2  k = (r,s,c), Cin >= 16 (one wrap per chunk at most)
+//   1  slice-major k = (c/16, r, s, c%16), Cin % 16 == 0    3  1x1 kernel, pad 0: no taps, no border
+template <int BM, int BN, int WGM, int WGN, int KMODE, bool ABL = false>
 __global__ void __launch_bounds__(256)
 conv_mfma_kernel(const ConvParams p) {
     static_assert(WGM * WGN == 4, "four waves per workgroup");
     constexpr int WM = BM / WGM, WN = BN / WGN;
     constexpr int TM = WM / 32, TN = WN / 32;
     constexpr int AIT = BM / 64, BIT = BN / 64;
-    __shared__ __attribute__((aligned(16))) float lds[2 * (BM + BN) * CLD];
-    float* As = lds;                      // [2][BM][CLD]
-    float* Bs = lds + 2 * BM * CLD;       // [2][BN][CLD]
+    // Operand tiles land in LDS by direct-to-LDS loads (buffer_load ... lds): a wave instruction writes 64 lanes
+    // x 16 B = 1 KB contiguous, i.e. 16 rows x 4 slots, lane l -> slot l.  Slot s of row m holds k-quad
+    // s ^ ((m >> 2) & 3): with that swizzle the ds_read_b128 fragment reads (lanes = consecutive rows, same
+    // k-quad) hit 16 distinct 16-byte bank groups per service group, so no padding is needed and no VGPRs or
+    // ds_write instructions are spent on staging.  The staging epilogue re-uses the same bytes (SLD = WN + 4).
+    constexpr int NBUF = 3;               // LDS ring: chunk kc is consumed while kc+1 and kc+2 are in flight
+    constexpr int STAGE_FLOATS = 4 * 32 * (BN / WGN + 4);
+    constexpr int OPER_FLOATS = NBUF * (BM + BN) * CLD;
+    __shared__ __attribute__((aligned(16))) float lds[OPER_FLOATS > STAGE_FLOATS ? OPER_FLOATS : STAGE_FLOATS];
+    float* As = lds;                      // [NBUF][BM][16]
+    float* Bs = lds + NBUF * BM * CLD;    // [NBUF][BN][16]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WGN, wn = wave % WGN;
@@ -76,8 +87,9 @@ conv_mfma_kernel(const ConvParams p) {
         __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.w), 0, (unsigned)((int64_t)p.Cout * p.Kpad * 4), 0x00020000);
     constexpr unsigned OOB = 0xFFFFFFFFu;
 
-    // per-thread rows (tid>>2) + 64*it and k-quad (tid&3)
-    const int kq = tid & 3, lrow = tid >> 2;
+    // DMA lane mapping: wave w, instruction `it` covers rows (it*4 + w)*16 .. +15; lane l -> row + (l >> 2), slot l & 3
+    const int lrow = wave * 16 + (lane >> 2);            // + 64 * it
+    const int kq = (lane & 3) ^ ((lrow >> 2) & 3);       // k-quad stored in this lane's slot (same for every it)
     int a_hi0[AIT], a_wi0[AIT], a_pix[AIT];
     bool a_ok[AIT];
 #pragma unroll
@@ -105,7 +117,7 @@ conv_mfma_kernel(const ConvParams p) {
     //              chunks and is served by L1/L2 instead of the fabric (measured: conv4_x 3x3 fetched 8.5x its
     //              input with korder 0).
     int tk = kq * 4, tr, ts, tc;
-    if (p.korder == 0) {
+    if (KMODE != 1) {
         const int rs = tk / p.Cin;
         tc = tk - rs * p.Cin;
         tr = rs / p.kw;
@@ -117,8 +129,13 @@ conv_mfma_kernel(const ConvParams p) {
     }
     unsigned va[AIT];
     auto tap_offsets = [&]() {
-        const int tapoff = (tr * p.W + ts) * p.in_cstride + tc;
         const bool kok = tk < p.K;
+        if (KMODE == 3) {
+#pragma unroll
+            for (int it = 0; it < AIT; ++it) va[it] = (kok && a_ok[it]) ? (unsigned)(a_pix[it] + tk) * 4u : OOB;
+            return;
+        }
+        const int tapoff = (tr * p.W + ts) * p.in_cstride + tc;
 #pragma unroll
         for (int it = 0; it < AIT; ++it) {
             const int hi = a_hi0[it] + tr, wi = a_wi0[it] + ts;
@@ -128,34 +145,46 @@ conv_mfma_kernel(const ConvParams p) {
     };
     auto tap_advance = [&]() {
         tk += CBK;
-        if (p.korder == 0) {
+        if (KMODE == 0) {
             tc += CBK;
             while (tc >= p.Cin) {
                 tc -= p.Cin;
                 if (++ts == p.kw) { ts = 0; ++tr; }
             }
-        } else if (++ts == p.kw) {
-            ts = 0;
-            if (++tr == p.kh) { tr = 0; tc += CBK; }
+        } else if (KMODE == 2) {
+            tc += CBK;
+            if (tc >= p.Cin) {
+                tc -= p.Cin;
+                if (++ts == p.kw) { ts = 0; ++tr; }
+            }
+        } else if (KMODE == 1) {
+            if (++ts == p.kw) {
+                ts = 0;
+                if (++tr == p.kh) { tr = 0; tc += CBK; }
+            }
         }
 #pragma unroll
         for (int it = 0; it < BIT; ++it) vb[it] = vb[it] == OOB ? OOB : vb[it] + CBK * 4u;
     };
 
-    u32x4 ga[AIT], gb[BIT];
-    auto gload = [&]() {
-#pragma unroll
-        for (int it = 0; it < AIT; ++it) ga[it] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_a, va[it], 0, 0);
-#pragma unroll
-        for (int it = 0; it < BIT; ++it) gb[it] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_b, vb[it], 0, 0);
+    // One chunk = AIT + BIT direct-to-LDS loads per wave, issued from inline asm: hipcc models an LDS-DMA builtin
+    // as an LDS store and puts `s_waitcnt vmcnt(0)` in front of the next ds_read (observed in the .s), which
+    // would expose the full memory latency every chunk.  Hidden in asm, the loads stay in flight across the
+    // fragment reads, the MFMAs and the barrier; completion is tracked by hand with counted vmcnt waits (the
+    // loop issues no other VMEM instruction).  M0 (LDS base of the 1 KB slab) is written in the same statement.
+    constexpr int NL = AIT + BIT;  // loads per wave per chunk
+    const unsigned lds_a = (unsigned)(uintptr_t)(__attribute__((address_space(3))) float*)As;
+    const unsigned lds_b = (unsigned)(uintptr_t)(__attribute__((address_space(3))) float*)Bs;
+    auto dma1 = [&](const __amdgpu_buffer_rsrc_t& rsrc, unsigned voff, unsigned lds_byte) {
+        const unsigned m0v = __builtin_amdgcn_readfirstlane(lds_byte);
+        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, 0 offen lds"
+                     :: "v"(voff), "s"(rsrc), "s"(m0v) : "memory");
     };
-    auto lstore = [&](int buf) {
+    auto dma = [&](int buf) {
 #pragma unroll
-        for (int it = 0; it < AIT; ++it)
-            *reinterpret_cast<u32x4*>(As + (buf * BM + lrow + it * 64) * CLD + kq * 4) = ga[it];
+        for (int it = 0; it < AIT; ++it) dma1(rsrc_a, va[it], lds_a + ((buf * BM + (it * 4 + wave) * 16) * CLD) * 4);
 #pragma unroll
-        for (int it = 0; it < BIT; ++it)
-            *reinterpret_cast<u32x4*>(Bs + (buf * BN + lrow + it * 64) * CLD + kq * 4) = gb[it];
+        for (int it = 0; it < BIT; ++it) dma1(rsrc_b, vb[it], lds_b + ((buf * BN + (it * 4 + wave) * 16) * CLD) * 4);
     };
 
     f32x16 acc[TM][TN];
@@ -168,16 +197,28 @@ conv_mfma_kernel(const ConvParams p) {
 
     const int lr = lane & 31, lh = lane >> 5;
     const int nk = p.Kpad / CBK;
-    // One barrier per 16-deep chunk.  Iteration kc: fragments of chunk kc LDS->registers, loads of chunk kc+1
-    // issued with offsets computed one iteration earlier (no VALU in front of them), offsets of chunk kc+2
-    // computed in the shadow of the 32 MFMAs, then chunk kc+1 registers->LDS (other buffer) and the barrier.
-    // Loads/stores past the last chunk are harmless (range check -> zeros into a buffer nobody reads).
     tap_offsets();
-    gload();
+    dma(0);
     tap_advance();
     tap_offsets();
-    lstore(0);
-    __syncthreads();
+    dma(1);
+    tap_advance();
+    tap_offsets();
+    // fragment read offsets (floats): row r, k-quads 2*lh and 2*lh+1 live in slots (2*lh)^g and (2*lh+1)^g, g = (r>>2)&3
+    int fa_off[TM][2], fb_off[TN][2];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int r = wm * WM + i * 32 + lr, g = (r >> 2) & 3;
+        fa_off[i][0] = r * CLD + (((2 * lh) ^ g) << 2);
+        fa_off[i][1] = r * CLD + (((2 * lh + 1) ^ g) << 2);
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int r = wn * WN + j * 32 + lr, g = (r >> 2) & 3;
+        fb_off[j][0] = r * CLD + (((2 * lh) ^ g) << 2);
+        fb_off[j][1] = r * CLD + (((2 * lh + 1) ^ g) << 2);
+    }
+    asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" :: "n"(NL) : "memory");   // chunk 0 landed (chunk 1 still in flight)
     float4 fa[TM][2], fb[TN][2];
     if (ABL) {
 #pragma unroll
@@ -185,27 +226,31 @@ conv_mfma_kernel(const ConvParams p) {
 #pragma unroll
         for (int j = 0; j < TN; ++j) fb[j][0] = fb[j][1] = float4{1.f, 2.f, 3.f, 4.f};
     }
+    // One barrier per 16-deep chunk.  Iteration kc: the direct-to-LDS loads of chunk kc+2 are issued first
+    // (offsets computed one iteration earlier, no VALU in front of them), then the fragments of chunk kc are
+    // read, offsets of chunk kc+3 are computed in the shadow of the 32 MFMAs, and the iteration ends with
+    // `s_waitcnt vmcnt(NL)` (chunk kc+1 landed, chunk kc+2 may still be in flight) + s_barrier.  Loads past
+    // the last chunk are harmless (range check -> zeros into a ring slot nobody reads).
+    int buf = 0, buf2 = 2;
     for (int kc = 0; kc < nk; ++kc) {
-        const int buf = kc & 1;
+        if (!ABL || !(p.ablate & (1 | 128))) dma(buf2);
         if (!ABL || !(p.ablate & 8)) {
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
-                const float4* q = reinterpret_cast<const float4*>(As + (buf * BM + wm * WM + i * 32 + lr) * CLD + lh * 8);
-                fa[i][0] = q[0];
-                fa[i][1] = q[1];
+                fa[i][0] = *reinterpret_cast<const float4*>(As + buf * BM * CLD + fa_off[i][0]);
+                fa[i][1] = *reinterpret_cast<const float4*>(As + buf * BM * CLD + fa_off[i][1]);
             }
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
-                const float4* q = reinterpret_cast<const float4*>(Bs + (buf * BN + wn * WN + j * 32 + lr) * CLD + lh * 8);
-                fb[j][0] = q[0];
-                fb[j][1] = q[1];
+                fb[j][0] = *reinterpret_cast<const float4*>(Bs + buf * BN * CLD + fb_off[j][0]);
+                fb[j][1] = *reinterpret_cast<const float4*>(Bs + buf * BN * CLD + fb_off[j][1]);
             }
         }
-        if (!ABL || !(p.ablate & 1)) {
-            gload();
+        if (!ABL || !(p.ablate & (1 | 256))) {
             tap_advance();
             tap_offsets();
         }
+        if (ABL && (p.ablate & 64)) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int h = 0; h < 2; ++h)
 #pragma unroll
@@ -218,9 +263,13 @@ conv_mfma_kernel(const ConvParams p) {
                         const float b = kk == 0 ? fb[j][h].x : kk == 1 ? fb[j][h].y : kk == 2 ? fb[j][h].z : fb[j][h].w;
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[i][j], 0, 0, 0);
                     }
-        if (!ABL || !(p.ablate & 2)) lstore(buf ^ 1);
-        if (!ABL || !(p.ablate & 4)) __syncthreads();
+        if (ABL && (p.ablate & 64)) __builtin_amdgcn_s_setprio(0);
+        if (!ABL || !(p.ablate & 4))
+            asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" :: "n"(NL) : "memory");
+        buf = buf == NBUF - 1 ? 0 : buf + 1;
+        buf2 = buf2 == NBUF - 1 ? 0 : buf2 + 1;
     }
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");   // drain the over-issued loads before LDS is re-used
 
     // ---- fused epilogue.  MFMA C layout: col = lane & 31, row = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5), i.e. a
     // lane owns a 16-row strip of ONE channel.  Per-lane stores of that layout are 4-byte, row-strided and
@@ -232,8 +281,7 @@ conv_mfma_kernel(const ConvParams p) {
         constexpr int SLD = WN + 4;                 // staging row stride (floats)
         constexpr int QN = WN / 4;                  // float4 per staged row
         constexpr int RPI = 64 / QN;                // rows covered by one wave-wide float4 access
-        float* st = lds + wave * (32 * SLD);        // 32 x WN per wave; 4 * 32 * SLD <= 2 * (BM + BN) * CLD
-        static_assert(4 * 32 * SLD <= 2 * (BM + BN) * CLD, "staging fits in the operand buffers");
+        float* st = lds + wave * (32 * SLD);        // 32 x WN per wave, re-using the (dead) operand buffers
         const int qc = lane % QN, qr = lane / QN;
         const int n0 = n_base + wn * WN + qc * 4;
         const bool nok = n0 < p.Cout;
@@ -304,8 +352,8 @@ conv_mfma_kernel(const ConvParams p) {
     }
 }
 
-template <int BM, int BN, int WGM, int WGN, bool ABL = false>
-static int launch_cfg(ConvParams p, hipStream_t stream) {
+template <int BM, int BN, int WGM, int WGN, int KMODE, bool ABL = false>
+static int launch_km(ConvParams p, hipStream_t stream) {
     p.tiles_m = (p.M + BM - 1) / BM;
     p.tiles_n = (p.Cout + BN - 1) / BN;
     const int64_t blocks = (int64_t)p.tiles_m * p.tiles_n;
@@ -315,10 +363,18 @@ static int launch_cfg(ConvParams p, hipStream_t stream) {
         snprintf(tag, sizeof(tag), "M=%d K=%d N=%d k%d s%d t%dx%d", p.M, p.K, p.Cout, p.kh, p.stride, BM, BN);
         prof_before(0, 2.0 * (double)p.M * (double)(p.kh * p.kw * p.Cin_real) * (double)p.Cout, stream, tag);
     }
-    hipLaunchKernelGGL((conv_mfma_kernel<BM, BN, WGM, WGN, ABL>), dim3((unsigned)blocks), dim3(256), 0, stream, p);
+    hipLaunchKernelGGL((conv_mfma_kernel<BM, BN, WGM, WGN, KMODE, ABL>), dim3((unsigned)blocks), dim3(256), 0, stream, p);
     prof_after(0, stream);
     MM_LAUNCH_CHECK();
     return MM_OK;
+}
+
+template <int BM, int BN, int WGM, int WGN>
+static int launch_cfg(const ConvParams& p, hipStream_t stream) {
+    if (p.kh == 1 && p.kw == 1 && p.pad == 0) return launch_km<BM, BN, WGM, WGN, 3>(p, stream);
+    if (p.korder == 1) return launch_km<BM, BN, WGM, WGN, 1>(p, stream);
+    if (p.Cin >= CBK) return launch_km<BM, BN, WGM, WGN, 2>(p, stream);
+    return launch_km<BM, BN, WGM, WGN, 0>(p, stream);
 }
 
 int conv_forward(const ConvParams& p0, hipStream_t stream) {
@@ -341,13 +397,12 @@ int conv_forward(const ConvParams& p0, hipStream_t stream) {
     const int64_t m128 = (p.M + 127) / 128, m256 = (p.M + 255) / 256;
     const int64_t n128 = (p.Cout + 127) / 128, n64 = (p.Cout + 63) / 64;
     int cfg = p.force_tile;
-    if (cfg >= 16) {  // measurement-only: 128x128 with ablation bits (cfg - 16)
+    if (cfg >= 16) {  // measurement-only: 128x128 with experiment bits (cfg - 16)
         p.ablate = cfg - 16;
-        return launch_cfg<128, 128, 2, 2, true>(p, stream);
+        return launch_km<128, 128, 2, 2, 1, true>(p, stream);  // slice-major 3x3 shapes only
     }
     if (cfg == 0) {
         if (p.Cout > 64 && m128 * n128 >= 512) cfg = 1;
-        else if (p.Cout <= 64 && m256 * n64 >= 512) cfg = 4;
         else if (m128 * n64 >= 512) cfg = 2;
         else cfg = 3;
     }
