@@ -98,6 +98,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--clips", type=int, default=32, help="64-frame clips per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL; gloo only for "
+                    "plumbing tests of the multi-process path on a single GPU, together with --same-device)")
+    ap.add_argument("--same-device", action="store_true", help="testing only: every rank uses cuda:0")
     ap.add_argument("--from-u8", action="store_true",
                     help="start every step from the raw boundary (uint8 112x112x3 aligned faces in HBM): adds the "
                          "PIL-exact on-GPU preprocessing to the timed region")
@@ -111,8 +114,8 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world)
+        torch.cuda.set_device(0 if args.same_device else local_rank)
+        dist.init_process_group(backend=args.backend, rank=rank, world_size=world)
     else:
         torch.cuda.set_device(0)
     device = torch.device("cuda", torch.cuda.current_device())
@@ -181,6 +184,17 @@ def main():
     phase_ms = ms[1] + ms[2]
     phase_gbs = (work[1] + work[2]) / (phase_ms * 1e-3) / 1e9
 
+    # HBM traffic of the conv engine cannot be read live (PMC counters need rocprofv3): tools/pmc_bench_traffic.sh
+    # measures it for this exact command and the summary is committed under profiles/; it is reported here only
+    # when it was taken at the same clips-per-GPU.
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "r01_conv_traffic_%dclips.json" % args.clips)
+    if os.path.exists(tpath):
+        with open(tpath) as f:
+            tj = json.load(f)
+        if tj.get("clips_per_gpu") == args.clips:
+            traffic = tj["bytes_per_step"]
+
     result = {
         "metric": "face-frames/sec end-to-end (phase-diff + ResNet50 + 2-stream GRU), 64-frame clips",
         "value": world * n_frames * args.steps / dt,
@@ -202,7 +216,9 @@ def main():
                    "clips_per_gpu": args.clips, "frames_per_step_per_gpu": n_frames, "parallelism": "videos sharded, dp%d" % world},
         "roofline": {"bound": "mfma", "kernel": "conv_mfma_kernel (fp32 implicit-GEMM conv/GEMM engine, all %d launches of one step)" % launches[0],
                      "achieved": conv_tflops, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                     "frac": conv_tflops / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
+                     "frac": conv_tflops / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic,
+                     "traffic_note": "HBM bytes per step over all conv launches, rocprofv3 PMC (2*FETCH_SIZE + WRITE_SIZE)*1024, "
+                                     "from profiles/ (not live)" if traffic else None,
                      "flops_per_step": work[0], "ms_per_step": ms[0], "launches_per_step": int(launches[0])},
         "roofline_phase": {"bound": "hbm", "kernel": "pyramid_kernel + phase_window_kernel<48|24>",
                            "achieved": phase_gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": phase_gbs / PEAK_HBM_GBS,
