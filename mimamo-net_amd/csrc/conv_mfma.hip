@@ -38,6 +38,7 @@ constexpr int CLD = 16;   // LDS row = one 16-float chunk; the four 16-byte slot
 // KMODE selects the tap iteration at compile time (straight-line VALU in the hot loop):
 //   0  k = (r,s,c), any Cin % 4 == 0 (stem: Cin = 4)      2  k = (r,s,c), Cin >= 16 (one wrap per chunk at most)
 //   1  slice-major k = (c/16, r, s, c%16), Cin % 16 == 0    3  1x1 kernel, pad 0: no taps, no border
+//   4  Cin == 4 and kw >= 4 (the 7x7 stem on NHWC4): a k-quad is one tap, four taps per chunk
 template <int BM, int BN, int WGM, int WGN, int KMODE, bool ABL = false>
 __global__ void __launch_bounds__(256)
 conv_mfma_kernel(const ConvParams p) {
@@ -162,6 +163,9 @@ conv_mfma_kernel(const ConvParams p) {
                 ts = 0;
                 if (++tr == p.kh) { tr = 0; tc += CBK; }
             }
+        } else if (KMODE == 4) {
+            ts += CBK / 4;
+            if (ts >= p.kw) { ts -= p.kw; ++tr; }
         }
 #pragma unroll
         for (int it = 0; it < BIT; ++it) vb[it] = vb[it] == OOB ? OOB : vb[it] + CBK * 4u;
@@ -374,6 +378,7 @@ static int launch_cfg(const ConvParams& p, hipStream_t stream) {
     if (p.kh == 1 && p.kw == 1 && p.pad == 0) return launch_km<BM, BN, WGM, WGN, 3>(p, stream);
     if (p.korder == 1) return launch_km<BM, BN, WGM, WGN, 1>(p, stream);
     if (p.Cin >= CBK) return launch_km<BM, BN, WGM, WGN, 2>(p, stream);
+    if (p.Cin == 4 && p.kw >= 4) return launch_km<BM, BN, WGM, WGN, 4>(p, stream);
     return launch_km<BM, BN, WGM, WGN, 0>(p, stream);
 }
 
