@@ -7,11 +7,11 @@ namespace mm {
 thread_local int g_last_hip_error = 0;
 
 int launch_pyramid(const mm_pyramid* h, const float* frames, int64_t n, int64_t group, float* c1, int64_t gs1,
-                   int64_t is1, int64_t bs1, float* c2, int64_t gs2, int64_t is2, int64_t bs2, hipStream_t stream);
+                   int64_t is1, int64_t bs1, float* c2, int64_t gs2, int64_t is2, int64_t bs2, int polar, hipStream_t stream);
 int pyramid_table_floats();
 int pack_pyramid_tables(const PyramidTables& t, std::vector<float>& packed);
 int launch_phase_window(const float* coeff, const int32_t* ids, int64_t img_stride, int64_t band_stride, int64_t J,
-                        int W, float* out, int out_nhwc, int out_cstride, int out_coffset, hipStream_t stream);
+                        int W, float* out, int out_nhwc, int out_cstride, int out_coffset, int polar, hipStream_t stream);
 
 static int check_config(int size, int height, int nbands, int scale_factor) {
     if (size <= 0 || height < 1 || nbands < 1 || scale_factor < 1) return MM_ERR_INVALID_ARG;
@@ -97,7 +97,7 @@ int mm_pyramid_destroy(mm_pyramid_t* h) {
 int mm_pyramid_build(mm_pyramid_t* h, const float* frames, int64_t n, float* c1, int64_t is1, int64_t bs1, float* c2,
                      int64_t is2, int64_t bs2, void* stream) {
     if (!h || n < 0 || (n > 0 && (!frames || !c1 || !c2))) return MM_ERR_INVALID_ARG;
-    return mm::launch_pyramid(h, frames, n, n, c1, 0, is1, bs1, c2, 0, is2, bs2, (hipStream_t)stream);
+    return mm::launch_pyramid(h, frames, n, n, c1, 0, is1, bs1, c2, 0, is2, bs2, 0, (hipStream_t)stream);
 }
 
 // build_pyramid layout (phase_difference_extractor.py:82-85): image (b,p), band k -> plane [b][k][p],
@@ -108,7 +108,7 @@ int mm_pyramid_build_batch(mm_pyramid_t* h, const float* im_batch, int64_t B, in
     const int64_t S = h->cfg.size, nb = h->cfg.nbands;
     const int64_t plane1 = S * S * 2, plane2 = (S / 2) * (S / 2) * 2;
     return mm::launch_pyramid(h, im_batch, B * P, P, c1, nb * P * plane1, plane1, P * plane1, c2, nb * P * plane2,
-                              plane2, P * plane2, (hipStream_t)stream);
+                              plane2, P * plane2, 0, (hipStream_t)stream);
 }
 
 int mm_phase_extract(mm_pyramid_t* h, const float* coeff, const int32_t* ids, int64_t img_stride, int64_t band_stride,
@@ -118,7 +118,7 @@ int mm_phase_extract(mm_pyramid_t* h, const float* coeff, const int32_t* ids, in
     if (W != h->cfg.size && W != h->cfg.size / 2) return MM_ERR_UNSUPPORTED;
     if (out_nhwc && (out_cstride < out_coffset + 2 * (P - 1) || out_coffset < 0)) return MM_ERR_INVALID_ARG;
     return mm::launch_phase_window(coeff, ids, img_stride, band_stride, J, W, out, out_nhwc, out_cstride, out_coffset,
-                                   (hipStream_t)stream);
+                                   0, (hipStream_t)stream);
 }
 
 int64_t mm_phase_workspace_bytes(mm_pyramid_t* h, int64_t n) {
@@ -136,13 +136,17 @@ int mm_phase_diff_frames(mm_pyramid_t* h, const float* frames, int64_t n, const 
     const int64_t plane1 = S * S * 2, plane2 = (S / 2) * (S / 2) * 2;
     float* c1 = (float*)workspace;           // [n][nb][S][S][2]
     float* c2 = c1 + n * nb * plane1;        // [n][nb][S/2][S/2][2]
-    int rc = mm::launch_pyramid(h, frames, n, n, c1, 0, nb * plane1, plane1, c2, 0, nb * plane2, plane2,
+    // fused path: the workspace planes hold (phase, magnitude) -- atan2/sqrt once per unique frame
+    int rc = mm::launch_pyramid(h, frames, n, n, c1, 0, nb * plane1, plane1, c2, 0, nb * plane2, plane2, 1,
                                 (hipStream_t)stream);
     if (rc != MM_OK) return rc;
-    rc = mm_phase_extract(h, c1, ids, nb * plane1, plane1, J, 13, (int)S, out0, out0_nhwc, out0_cstride, out0_coffset, stream);
+    if (out0_nhwc && (out0_cstride < out0_coffset + 24 || out0_coffset < 0)) return MM_ERR_INVALID_ARG;
+    if (out1_nhwc && (out1_cstride < out1_coffset + 24 || out1_coffset < 0)) return MM_ERR_INVALID_ARG;
+    rc = mm::launch_phase_window(c1, ids, nb * plane1, plane1, J, (int)S, out0, out0_nhwc, out0_cstride, out0_coffset, 1,
+                                 (hipStream_t)stream);
     if (rc != MM_OK) return rc;
-    return mm_phase_extract(h, c2, ids, nb * plane2, plane2, J, 13, (int)S / 2, out1, out1_nhwc, out1_cstride,
-                            out1_coffset, stream);
+    return mm::launch_phase_window(c2, ids, nb * plane2, plane2, J, (int)S / 2, out1, out1_nhwc, out1_cstride,
+                                   out1_coffset, 1, (hipStream_t)stream);
 }
 
 }  // extern "C"

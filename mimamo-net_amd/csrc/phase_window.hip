@@ -15,6 +15,7 @@
 // un-normalised Gaussian and zero padding (Q5).  Not reproduced: the mag<=0 host assert (Q11)
 // and the dead mean-centring of the denoised phase (Q12).
 #include "mm_common.h"
+#include "phase_math.h"
 
 namespace mm {
 
@@ -37,7 +38,9 @@ struct WinCfg {
     static constexpr int LDS_FLOATS = 2 * IN_PLANE + 2 * TMP_PLANE + 64 * (P - 1);
 };
 
-template <int W>
+// POLAR: the planes already hold (phase, magnitude) pairs -- written by the pyramid kernel on the fused path, which
+// computes atan2/sqrt once per unique frame instead of once per window containing it (13x).
+template <int W, bool POLAR>
 __global__ void __launch_bounds__(WinCfg<W>::NTHREADS)
 phase_window_kernel(const float* __restrict__ coeff, const int32_t* __restrict__ ids, int64_t img_stride,
                     int64_t band_stride, float* __restrict__ out, int out_nhwc, int out_cstride, int out_coffset) {
@@ -76,16 +79,25 @@ phase_window_kernel(const float* __restrict__ coeff, const int32_t* __restrict__
             float num[PX], den[PX];
 #pragma unroll
             for (int p = 0; p < PX; ++p) {
-                const float ph = atan2f(im[p], re[p]);
-                const float mag = sqrtf(im[p] * im[p] + re[p] * re[p]) + 1e-10f;
+                float ph, mag;
+                if (POLAR) {
+                    ph = re[p];
+                    mag = im[p];
+                } else {
+                    to_polar(re[p], im[p], ph, mag);
+                }
                 float up = ph;
                 if (i == 0) {
                     cum[p] = 0.f;
                 } else {
                     // torch_unwrap: ddmod = fmod(dd + pi, 2 pi) - pi; (ddmod == -pi & dd > 0) -> pi;
                     // corr = ddmod - dd, zeroed where |dd| < pi; up = p + cumsum(corr)
+                    // fmod(x, 2 pi) for x = dd + pi in [-pi, 3 pi] (dd is a difference of two atan2 values) is x
+                    // when x < 2 pi (C fmod keeps the sign of x) and x - 2 pi otherwise, an exact subtraction
+                    // (Sterbenz) -- bit-identical to fmodf without its ~25-instruction expansion.
                     const float dd = ph - prev_phase[p];
-                    float ddmod = fmodf(dd + PI_F, TWO_PI_F) - PI_F;
+                    const float xs = dd + PI_F;
+                    float ddmod = (xs >= TWO_PI_F ? xs - TWO_PI_F : xs) - PI_F;
                     if (ddmod == -PI_F && dd > 0.f) ddmod = PI_F;
                     float corr = ddmod - dd;
                     if (fabsf(dd) < PI_F) corr = 0.f;
@@ -195,7 +207,7 @@ static int upload_gauss() {
 }
 
 int launch_phase_window(const float* coeff, const int32_t* ids, int64_t img_stride, int64_t band_stride, int64_t J,
-                        int W, float* out, int out_nhwc, int out_cstride, int out_coffset, hipStream_t stream) {
+                        int W, float* out, int out_nhwc, int out_cstride, int out_coffset, int polar, hipStream_t stream) {
     if (J <= 0) return MM_OK;
     static bool gauss_ready = false;
     if (!gauss_ready) {
@@ -205,15 +217,15 @@ int launch_phase_window(const float* coeff, const int32_t* ids, int64_t img_stri
     }
     const dim3 grid((unsigned)(2 * J));
     prof_before(2, (double)J * 2 * (P - 1) * W * W * 4, stream);  // algorithmic write: 24 phase-difference planes
-    if (W == 48) {
-        hipLaunchKernelGGL(phase_window_kernel<48>, grid, dim3(WinCfg<48>::NTHREADS), 0, stream, coeff, ids, img_stride,
-                           band_stride, out, out_nhwc, out_cstride, out_coffset);
-    } else if (W == 24) {
-        hipLaunchKernelGGL(phase_window_kernel<24>, grid, dim3(WinCfg<24>::NTHREADS), 0, stream, coeff, ids, img_stride,
-                           band_stride, out, out_nhwc, out_cstride, out_coffset);
-    } else {
-        return MM_ERR_UNSUPPORTED;
-    }
+#define MM_WIN(WW, PP)                                                                                                  \
+    hipLaunchKernelGGL((phase_window_kernel<WW, PP>), grid, dim3(WinCfg<WW>::NTHREADS), 0, stream, coeff, ids, img_stride, \
+                       band_stride, out, out_nhwc, out_cstride, out_coffset)
+    if (W == 48 && polar) MM_WIN(48, true);
+    else if (W == 48) MM_WIN(48, false);
+    else if (W == 24 && polar) MM_WIN(24, true);
+    else if (W == 24) MM_WIN(24, false);
+    else return MM_ERR_UNSUPPORTED;
+#undef MM_WIN
     prof_after(2, stream);
     MM_LAUNCH_CHECK();
     return MM_OK;

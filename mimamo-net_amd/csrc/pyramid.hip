@@ -19,6 +19,7 @@
 // All products run on the fp32 matrix cores (v_mfma_f32_16x16x4_f32: exact fp32 FMA chains), one
 // 256-thread workgroup per (frame, band), operands staged in LDS with bank-conflict-free strides.
 #include "mm_common.h"
+#include "phase_math.h"
 
 namespace mm {
 
@@ -86,7 +87,7 @@ __device__ __forceinline__ f32x4 tile_real(int lane, FA a, FB b) {
 // is 2H x 2H, signed frequency f = index - H.  BAND 0: half plane fv in [0,H), rows r = fu + H.
 // BAND 1: half plane fu in [0,H), columns c = fv + H.
 template <int H, int BAND>
-__device__ __forceinline__ void band_pass(float* lds, const float* __restrict__ mask, float* __restrict__ out_plane) {
+__device__ __forceinline__ void band_pass(float* lds, const float* __restrict__ mask, float* __restrict__ out_plane, int polar) {
     constexpr int N2 = 2 * H;
     constexpr int STEP = S / H;               // column step into E: exp(2 pi i f q / (2H)) = E[f][STEP*q]
     constexpr int MT = (H + 15) / 16;         // tiles covering the kept quadrant (3 / 2)
@@ -205,11 +206,20 @@ __device__ __forceinline__ void band_pass(float* lds, const float* __restrict__ 
         }
     }
     __syncthreads();
-    // ---- coalesced store of the [H][H][2] plane
+    // ---- coalesced store of the [H][H][2] plane: (re, im) pairs, or (phase, magnitude) on the fused path
     {
         const float4* src = reinterpret_cast<const float4*>(lds + L_S);
         float4* dst = reinterpret_cast<float4*>(out_plane);
-        for (int i = tid; i < H * H / 2; i += NT) dst[i] = src[i];
+        for (int i = tid; i < H * H / 2; i += NT) {
+            float4 v = src[i];
+            if (polar) {
+                float4 q;
+                to_polar(v.x, v.y, q.x, q.y);
+                to_polar(v.z, v.w, q.z, q.w);
+                v = q;
+            }
+            dst[i] = v;
+        }
     }
     __syncthreads();
 }
@@ -218,7 +228,7 @@ __device__ __forceinline__ void band_pass(float* lds, const float* __restrict__ 
 __global__ void __launch_bounds__(NT)
 pyramid_kernel(const float* __restrict__ tables, const float* __restrict__ frames, int64_t n, int64_t group,
                float* __restrict__ c1, int64_t group_stride1, int64_t img_stride1, int64_t band_stride1,
-               float* __restrict__ c2, int64_t group_stride2, int64_t img_stride2, int64_t band_stride2) {
+               float* __restrict__ c2, int64_t group_stride2, int64_t img_stride2, int64_t band_stride2, int polar) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     for (int i = tid; i < S * S; i += NT) {
@@ -269,17 +279,17 @@ pyramid_kernel(const float* __restrict__ tables, const float* __restrict__ frame
         float* o1 = c1 + grp * group_stride1 + pos * img_stride1 + band * band_stride1;
         float* o2 = c2 + grp * group_stride2 + pos * img_stride2 + band * band_stride2;
         if (band == 0) {
-            band_pass<48, 0>(lds, tables + OFF_M1B0, o1);
-            band_pass<24, 0>(lds, tables + OFF_M2B0, o2);
+            band_pass<48, 0>(lds, tables + OFF_M1B0, o1, polar);
+            band_pass<24, 0>(lds, tables + OFF_M2B0, o2, polar);
         } else {
-            band_pass<48, 1>(lds, tables + OFF_M1B1, o1);
-            band_pass<24, 1>(lds, tables + OFF_M2B1, o2);
+            band_pass<48, 1>(lds, tables + OFF_M1B1, o1, polar);
+            band_pass<24, 1>(lds, tables + OFF_M2B1, o2, polar);
         }
     }
 }
 
 int launch_pyramid(const mm_pyramid* h, const float* frames, int64_t n, int64_t group, float* c1, int64_t gs1,
-                   int64_t is1, int64_t bs1, float* c2, int64_t gs2, int64_t is2, int64_t bs2, hipStream_t stream) {
+                   int64_t is1, int64_t bs1, float* c2, int64_t gs2, int64_t is2, int64_t bs2, int polar, hipStream_t stream) {
     if (n <= 0) return MM_OK;
     static_assert(L_TOTAL * 4 <= 160 * 1024, "LDS budget");
     const int lds_bytes = L_TOTAL * 4;
@@ -293,7 +303,7 @@ int launch_pyramid(const mm_pyramid* h, const float* frames, int64_t n, int64_t 
     if (grid > 1024) grid = 1024;  // 256 CUs x 1 resident workgroup; the rest grid-strides
     prof_before(1, (double)n * (S * S * 4), stream);  // algorithmic read of the stage: one fp32 frame
     hipLaunchKernelGGL(pyramid_kernel, dim3((unsigned)grid), dim3(NT), lds_bytes, stream, h->d_tables, frames, n,
-                       group > 0 ? group : n, c1, gs1, is1, bs1, c2, gs2, is2, bs2);
+                       group > 0 ? group : n, c1, gs1, is1, bs1, c2, gs2, is2, bs2, polar);
     prof_after(1, stream);
     MM_LAUNCH_CHECK();
     return MM_OK;
