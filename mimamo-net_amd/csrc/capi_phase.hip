@@ -116,7 +116,8 @@ int mm_phase_extract(mm_pyramid_t* h, const float* coeff, const int32_t* ids, in
     if (!h || J < 0 || (J > 0 && (!coeff || !ids || !out))) return MM_ERR_INVALID_ARG;
     if (P != 13) return MM_ERR_UNSUPPORTED;  // num_phase = 12 (api/tester.py:28)
     if (W != h->cfg.size && W != h->cfg.size / 2) return MM_ERR_UNSUPPORTED;
-    if (out_nhwc && (out_cstride < out_coffset + 2 * (P - 1) || out_coffset < 0)) return MM_ERR_INVALID_ARG;
+    if (out_nhwc && (out_cstride < out_coffset + 2 * (P - 1) || out_coffset < 0 || (out_cstride | out_coffset) & 3))
+        return MM_ERR_INVALID_ARG;  // 16-byte channel groups
     return mm::launch_phase_window(coeff, ids, img_stride, band_stride, J, W, out, out_nhwc, out_cstride, out_coffset,
                                    0, (hipStream_t)stream);
 }
@@ -140,8 +141,8 @@ int mm_phase_diff_frames(mm_pyramid_t* h, const float* frames, int64_t n, const 
     int rc = mm::launch_pyramid(h, frames, n, n, c1, 0, nb * plane1, plane1, c2, 0, nb * plane2, plane2, 1,
                                 (hipStream_t)stream);
     if (rc != MM_OK) return rc;
-    if (out0_nhwc && (out0_cstride < out0_coffset + 24 || out0_coffset < 0)) return MM_ERR_INVALID_ARG;
-    if (out1_nhwc && (out1_cstride < out1_coffset + 24 || out1_coffset < 0)) return MM_ERR_INVALID_ARG;
+    if (out0_nhwc && (out0_cstride < out0_coffset + 24 || out0_coffset < 0 || (out0_cstride | out0_coffset) & 3)) return MM_ERR_INVALID_ARG;
+    if (out1_nhwc && (out1_cstride < out1_coffset + 24 || out1_coffset < 0 || (out1_cstride | out1_coffset) & 3)) return MM_ERR_INVALID_ARG;
     rc = mm::launch_phase_window(c1, ids, nb * plane1, plane1, J, (int)S, out0, out0_nhwc, out0_cstride, out0_coffset, 1,
                                  (hipStream_t)stream);
     if (rc != MM_OK) return rc;

@@ -22,7 +22,7 @@ namespace mm {
 constexpr int P = 13;          // window length (num_phase + 1)
 constexpr int TAP = 11, R = 5; // gaussian_kernel(std=2, tap=11), phase_utils.py:108-115
 constexpr int PX = 4;          // pixels per thread (one float4)
-constexpr int PADX = 8;        // left/right zero pad in floats (>= R, keeps float4 alignment)
+constexpr int PADX = 8;        // the row pass reads [x0-8, x0+12): two float4 slots of halo on each side
 
 __constant__ float c_gauss[TAP];  // exp(-d^2/8), d=-5..5 ; the 2-D kernel is its outer product
 
@@ -31,8 +31,11 @@ struct WinCfg {
     static constexpr int STRIPS = W / PX;          // strips per row
     static constexpr int ACTIVE = STRIPS * W;      // 576 (W=48) / 144 (W=24)
     static constexpr int NTHREADS = (ACTIVE + 63) / 64 * 64;
-    static constexpr int LDI = W + 2 * PADX;       // padded input row
-    static constexpr int IN_PLANE = W * LDI;
+    // input planes are stored WITHOUT row padding (lane l owns 16-byte slot l, so consecutive lanes hit consecutive
+    // banks on both the write and the row-pass reads; a padded 64-float row stride made 55 % of the LDS cycles bank
+    // conflicts).  Halo slots that fall outside the row are zeroed by a select instead of by padding.
+    static constexpr int LDI = W;
+    static constexpr int IN_PLANE = W * LDI + 2 * PADX;   // + slack so clamped halo reads stay in bounds
     static constexpr int TMP_ROWS = W + 2 * R;     // zero rows above/below
     static constexpr int TMP_PLANE = TMP_ROWS * W;
     static constexpr int LDS_FLOATS = 2 * IN_PLANE + 2 * TMP_PLANE + 64 * (P - 1);
@@ -108,18 +111,22 @@ phase_window_kernel(const float* __restrict__ coeff, const int32_t* __restrict__
                 num[p] = mag * up;
                 den[p] = mag;
             }
-            *reinterpret_cast<float4*>(in_num + y * C::LDI + PADX + x0) = float4{num[0], num[1], num[2], num[3]};
-            *reinterpret_cast<float4*>(in_den + y * C::LDI + PADX + x0) = float4{den[0], den[1], den[2], den[3]};
+            *reinterpret_cast<float4*>(in_num + y * C::LDI + x0) = float4{num[0], num[1], num[2], num[3]};
+            *reinterpret_cast<float4*>(in_den + y * C::LDI + x0) = float4{den[0], den[1], den[2], den[3]};
         }
         __syncthreads();
         // ---- row pass: tmp[y][x] = sum_d g[d] in[y][x+d]
         if (active) {
             float vn[PX + 2 * PADX], vd[PX + 2 * PADX];  // [x0-8, x0+12)
-            const float4* rn = reinterpret_cast<const float4*>(in_num + y * C::LDI + x0);
-            const float4* rd = reinterpret_cast<const float4*>(in_den + y * C::LDI + x0);
+            const float4 zero4 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int q = 0; q < (PX + 2 * PADX) / 4; ++q) {
-                const float4 a = rn[q], b = rd[q];
+                const int xs = x0 - PADX + 4 * q;                      // first float of this slot
+                const bool in_row = xs >= 0 && xs < W;                 // zero padding of the 11-tap blur (Q5)
+                const int off = y * C::LDI + (in_row ? xs : x0);
+                float4 a = *reinterpret_cast<const float4*>(in_num + off);
+                float4 b = *reinterpret_cast<const float4*>(in_den + off);
+                if (!in_row) { a = zero4; b = zero4; }
                 vn[4 * q] = a.x; vn[4 * q + 1] = a.y; vn[4 * q + 2] = a.z; vn[4 * q + 3] = a.w;
                 vd[4 * q] = b.x; vd[4 * q + 1] = b.y; vd[4 * q + 2] = b.z; vd[4 * q + 3] = b.w;
             }
@@ -177,23 +184,40 @@ phase_window_kernel(const float* __restrict__ coeff, const int32_t* __restrict__
     constexpr int NWAVES = C::NTHREADS / 64;
     const float LIM = 5.f * PI_F;
     if (active) {
+        float mean[P - 1];
 #pragma unroll
         for (int k = 0; k < P - 1; ++k) {
             float s = 0.f;
 #pragma unroll
             for (int w = 0; w < NWAVES; ++w) s += red[w * (P - 1) + k];
-            const float mean = s * (1.0f / (W * W));
-            float o[PX];
+            mean[k] = s * (1.0f / (W * W));
+        }
+        if (!out_nhwc) {
+            // reference layout [J, band*12 + k, y, x]: one float4 (4 adjacent pixels) per channel plane
 #pragma unroll
-            for (int p = 0; p < PX; ++p) o[p] = fminf(fmaxf(d[k][p] - mean, -LIM), LIM);
-            const int c = band * (P - 1) + k;
-            if (!out_nhwc) {
+            for (int k = 0; k < P - 1; ++k) {
+                float o[PX];
+#pragma unroll
+                for (int p = 0; p < PX; ++p) o[p] = fminf(fmaxf(d[k][p] - mean[k], -LIM), LIM);
+                const int c = band * (P - 1) + k;
                 float* dst = out + ((j * (2 * (P - 1)) + c) * W + y) * W + x0;
                 *reinterpret_cast<float4*>(dst) = float4{o[0], o[1], o[2], o[3]};
-            } else {
+            }
+        } else {
+            // channels-last: this band's 12 channels of a pixel are 48 contiguous bytes -> three 16-byte stores
+            // per pixel (scalar channel-strided stores amplified HBM writes 9x: every 4-byte store dirtied a sector)
 #pragma unroll
-                for (int p = 0; p < PX; ++p)
-                    out[((j * W + y) * W + x0 + p) * out_cstride + out_coffset + c] = o[p];
+            for (int p = 0; p < PX; ++p) {
+                float* dst = out + ((j * W + y) * W + x0 + p) * out_cstride + out_coffset + band * (P - 1);
+#pragma unroll
+                for (int q = 0; q < (P - 1) / 4; ++q) {
+                    float4 v;
+                    v.x = fminf(fmaxf(d[4 * q][p] - mean[4 * q], -LIM), LIM);
+                    v.y = fminf(fmaxf(d[4 * q + 1][p] - mean[4 * q + 1], -LIM), LIM);
+                    v.z = fminf(fmaxf(d[4 * q + 2][p] - mean[4 * q + 2], -LIM), LIM);
+                    v.w = fminf(fmaxf(d[4 * q + 3][p] - mean[4 * q + 3], -LIM), LIM);
+                    reinterpret_cast<float4*>(dst)[q] = v;
+                }
             }
         }
     }
