@@ -195,6 +195,12 @@ def main():
         if tj.get("clips_per_gpu") == args.clips:
             traffic = tj["bytes_per_step"]
 
+    ptraffic = None
+    ppath = os.path.join(ROOT, "profiles", "r01_phase_traffic_%dclips.json" % args.clips)
+    if os.path.exists(ppath):
+        with open(ppath) as f:
+            ptraffic = json.load(f).get("bytes_per_step")
+
     result = {
         "metric": "face-frames/sec end-to-end (phase-diff + ResNet50 + 2-stream GRU), 64-frame clips",
         "value": world * n_frames * args.steps / dt,
@@ -222,7 +228,7 @@ def main():
                      "flops_per_step": work[0], "ms_per_step": ms[0], "launches_per_step": int(launches[0])},
         "roofline_phase": {"bound": "hbm", "kernel": "pyramid_kernel + phase_window_kernel<48|24>",
                            "achieved": phase_gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": phase_gbs / PEAK_HBM_GBS,
-                           "traffic": None, "bytes_per_step": work[1] + work[2], "ms_per_step": phase_ms,
+                           "traffic": ptraffic, "bytes_per_step": work[1] + work[2], "ms_per_step": phase_ms,
                            "ms_pyramid": ms[1], "ms_window": ms[2]},
     }
     if rank == 0:
