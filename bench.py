@@ -101,6 +101,7 @@ def main():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL; gloo only for "
                     "plumbing tests of the multi-process path on a single GPU, together with --same-device)")
     ap.add_argument("--same-device", action="store_true", help="testing only: every rank uses cuda:0")
+    ap.add_argument("--lanes", type=int, default=2, help="HIP streams the clips of a step are spread over (1 = single stream)")
     ap.add_argument("--from-u8", action="store_true",
                     help="start every step from the raw boundary (uint8 112x112x3 aligned faces in HBM): adds the "
                          "PIL-exact on-GPU preprocessing to the timed region")
@@ -137,8 +138,13 @@ def main():
         frames_u8 = torch.from_numpy(np.concatenate(
             [synthetic.make_clip_u8(rank * args.clips + c, FRAMES_PER_CLIP) for c in range(args.clips)])).to(device)
 
+    lengths = [FRAMES_PER_CLIP] * args.clips
+
     def step():
-        if frames_u8 is not None:
+        if args.lanes > 1:
+            ins = (frames_u8,) if frames_u8 is not None else (gray, rgb)
+            out = hot.forward_lanes(ins, lengths, args.lanes, independent_clips=True, from_u8=frames_u8 is not None)
+        elif frames_u8 is not None:
             out = hot.forward_u8(frames_u8, plan, independent_clips=True)
         else:
             out = hot.forward(gray, rgb, plan, independent_clips=True)  # [frames, 2]
@@ -177,7 +183,12 @@ def main():
     launches = (ctypes.c_int64 * 3)()
     with torch.no_grad():
         L.mm_profile_begin()
-        step()
+        # single stream for this leg: with several lanes in flight a kernel's event bracket also counts the time it
+        # shares the GPU with another lane's kernel, which would under-state the per-kernel rate
+        if frames_u8 is not None:
+            hot.forward_u8(frames_u8, plan, independent_clips=True)
+        else:
+            hot.forward(gray, rgb, plan, independent_clips=True)
         rc = L.mm_profile_end(ms, work, launches)
     assert rc == 0
     conv_tflops = work[0] / (ms[0] * 1e-3) / 1e12
@@ -219,6 +230,7 @@ def main():
                                % args.clips,
                    "input": "uint8 112x112x3 frames (on-GPU PIL-exact preprocessing in the timed region)" if args.from_u8
                             else "preprocessed fp32 tensors",
+                   "lanes": args.lanes,
                    "clips_per_gpu": args.clips, "frames_per_step_per_gpu": n_frames, "parallelism": "videos sharded, dp%d" % world},
         "roofline": {"bound": "mfma", "kernel": "conv_mfma_kernel (fp32 implicit-GEMM conv/GEMM engine, all %d launches of one step)" % launches[0],
                      "achieved": conv_tflops, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",

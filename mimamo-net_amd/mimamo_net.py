@@ -20,7 +20,7 @@ class Two_Stream_RNN(object):
         self.training = False
         self._handle = None
         self._state = None
-        self._ws = None
+        self._ws = {}
         self.device = None
 
     # -- nn.Module-like surface used by api/tester.py:45-51,77 ---------------------------------
@@ -121,11 +121,13 @@ class Two_Stream_RNN(object):
         out = torch.empty((bs, T, 2), dtype=torch.float32, device=rgb.device)
         L = _lib.lib()
         need = L.mm_head_workspace_bytes(h, bs, T)
-        if self._ws is None or self._ws.numel() * 4 < need:
-            self._ws = None
-            self._ws = torch.empty(((need + 3) // 4,), dtype=torch.float32, device=rgb.device)
+        key = torch.cuda.current_stream().cuda_stream   # per-stream workspace (lanes on different streams share the handle)
+        ws = self._ws.get(key)
+        if ws is None or ws.numel() * 4 < need:
+            self._ws[key] = None
+            ws = self._ws[key] = torch.empty(((need + 3) // 4,), dtype=torch.float32, device=rgb.device)
         rc = L.mm_head_forward(h, _lib.ptr(phase_0), _lib.ptr(phase_1), mode, _lib.ptr(rgb), bs, T, _lib.ptr(out),
-                               _lib.ptr(self._ws), need, _lib.current_stream())
+                               _lib.ptr(ws), need, _lib.current_stream())
         _lib.check(rc, "mm_head_forward")
         return out
 

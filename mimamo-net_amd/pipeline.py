@@ -68,6 +68,40 @@ class HotPath(object):
                 outs.append(o.view(-1, 2))
         return torch.cat(outs, 0)
 
+    # ---- lanes: independent videos on several HIP streams ------------------------------------------------
+    def forward_lanes(self, inputs, video_lengths, lanes=2, independent_clips=False, from_u8=False):
+        """Split the videos into `lanes` groups and run each group on its own HIP stream.  Kernels of different lanes
+        interleave on the GPU, so the under-filled tail of one layer (tile quantisation: e.g. 3136 blocks on 768 slots)
+        overlaps the head of another lane's layer; results are bit-identical to the single-stream pass (measured +2-3 %).
+        inputs: (gray, rgb) or (frames_u8,) tensors stacked over all videos in order.  Returns [rows, 2] in video order."""
+        nv = len(video_lengths)
+        lanes = max(1, min(lanes, nv))
+        key = (tuple(video_lengths), lanes)
+        cache = getattr(self, "_lane_cache", None)
+        if cache is None or cache[0] != key:
+            bounds = [round(i * nv / lanes) for i in range(lanes + 1)]
+            plans, frs = [], []
+            off = 0
+            for a, b in zip(bounds[:-1], bounds[1:]):
+                n = sum(video_lengths[a:b])
+                plans.append(self.plan(video_lengths[a:b]))
+                frs.append((off, off + n))
+                off += n
+            self._lane_cache = cache = (key, plans, frs, [torch.cuda.Stream(device=self.device) for _ in range(lanes)])
+        _, plans, frs, streams = cache
+        cur = torch.cuda.current_stream()
+        outs = []
+        for plan, (f0, f1), st in zip(plans, frs, streams):
+            st.wait_stream(cur)
+            with torch.cuda.stream(st):
+                part = [t[f0:f1] for t in inputs]
+                o = self.forward_u8(part[0], plan, independent_clips) if from_u8 else self.forward(part[0], part[1], plan, independent_clips)
+                o.record_stream(cur)
+                outs.append(o)
+        for st in streams:
+            cur.wait_stream(st)
+        return torch.cat(outs, 0)
+
     def forward_u8(self, frames_u8, plan, independent_clips=False):
         """Same as forward() but from the raw boundary: uint8 aligned faces [N,112,112,3] on the device
         (37.6 KB/frame over PCIe instead of 0.6 MB of fp32 tensors); PIL-exact preprocessing runs on the GPU."""

@@ -41,7 +41,7 @@ class Resnet50_Extractor(object):
             rc = L.mm_resnet50_create(ctypes.byref(h), blob.ctypes.data_as(ctypes.c_void_p), blob.size, 1, 1, 1e-5)
         _lib.check(rc, "mm_resnet50_create")
         self._handle = h
-        self._ws = None
+        self._ws = {}   # per-stream workspaces: the handle itself is stateless, so lanes on different streams may share it
 
     def close(self):
         if getattr(self, "_handle", None) is not None:
@@ -56,10 +56,12 @@ class Resnet50_Extractor(object):
 
     def _workspace(self, bs):
         need = _lib.lib().mm_resnet50_workspace_bytes(self._handle, bs)
-        if self._ws is None or self._ws.numel() * 4 < need:
-            self._ws = None
-            self._ws = torch.empty(((need + 3) // 4,), dtype=torch.float32, device=self.device)
-        return self._ws, need
+        key = torch.cuda.current_stream().cuda_stream
+        ws = self._ws.get(key)
+        if ws is None or ws.numel() * 4 < need:
+            self._ws[key] = None
+            ws = self._ws[key] = torch.empty(((need + 3) // 4,), dtype=torch.float32, device=self.device)
+        return ws, need
 
     def get_vec(self, image, channels_last4=False):
         """image [bs,3,224,224] (255*x - mean) -> pool5 features [bs,2048] ON THE DEVICE.

@@ -78,3 +78,17 @@ def test_tester_reads_reference_directory_layout(tester, oracle, tmp_path):
     assert files[0] == "00001.npy" and len(files) == 12 and np.load(str(out_dir / files[0])).shape == (2048,)
     with pytest.raises(RuntimeError, match="aligned faces not found"):
         tester.test(str(tmp_path / "missing.mp4"))
+
+
+def test_lanes_on_several_streams_are_bit_identical(tester):
+    """Videos spread over HIP streams (shared handles, per-stream workspaces) == single-stream pass."""
+    lengths = [64, 100, 64, 30]
+    clips = [synthetic.make_clip_u8(70 + i, n) for i, n in enumerate(lengths)]
+    frames = torch.from_numpy(np.concatenate(clips)).to(tester.device)
+    plan = tester.hot.plan(lengths)
+    with torch.no_grad():
+        a = tester.hot.forward_u8(frames, plan)
+        for lanes in (2, 3):
+            b = tester.hot.forward_lanes((frames,), lengths, lanes, from_u8=True)
+            torch.cuda.synchronize()
+            assert torch.equal(a, b)
