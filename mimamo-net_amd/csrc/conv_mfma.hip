@@ -181,8 +181,9 @@ conv_mfma_kernel(const ConvParams p) {
     const unsigned lds_b = (unsigned)(uintptr_t)(__attribute__((address_space(3))) float*)Bs;
     auto dma1 = [&](const __amdgpu_buffer_rsrc_t& rsrc, unsigned voff, unsigned lds_byte) {
         const unsigned m0v = __builtin_amdgcn_readfirstlane(lds_byte);
-        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, 0 offen lds"
-                     :: "v"(voff), "s"(rsrc), "s"(m0v) : "memory");
+        unsigned keep;  // M0 is compiler-reserved: save it, point it at the slab, restore it, all in one statement
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(voff), "s"(rsrc), "s"(m0v) : "memory");
     };
     auto dma = [&](int buf) {
 #pragma unroll
