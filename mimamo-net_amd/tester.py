@@ -48,6 +48,46 @@ class Tester(object):
     def phase_diff_output(self, phase_batch, steerable_pyramid):
         return _phase_diff_output(phase_batch, steerable_pyramid)
 
+    def test_on_dataloader(self, dataloader, model=None, train_mean=None, train_std=None):
+        """Reference loop (api/tester.py:76-121) over batches `(phase_f [bs,T,13,48,48], rgb_f [bs,T,2048], label,
+        ranges [bs,2], names [bs])` as Snippet_Sampler + DataLoader produce them: windowed phase input (the 13x
+        redundant form), one GRU call per batch, assembly with later snippets overwriting earlier ones."""
+        import pandas as pd
+        if train_mean is not None or train_std is not None:
+            raise NotImplementedError("train_mean/train_std rescaling calls an undefined `correct` in the reference (tester.py:100)")
+        model = self.model if model is None else model
+        model.eval()
+        sample_names, sample_preds, sample_ranges = [], [], []
+        for data_batch in dataloader:
+            phase_f, rgb_f, _, ranges, names = data_batch
+            with torch.no_grad():
+                phase_f = torch.as_tensor(phase_f).float().to(self.device)
+                phase_0, phase_1 = self.phase_diff_output(phase_f, self.phase_difference_extractor)
+                rgb_f = torch.as_tensor(rgb_f).float().to(self.device)
+                output = model([phase_0, phase_1], rgb_f)
+            sample_names.append(np.asarray(names))
+            sample_ranges.append(np.asarray(ranges))
+            sample_preds.append(output.cpu().numpy())
+        sample_names = np.concatenate(sample_names, axis=0)
+        sample_preds = np.concatenate(sample_preds, axis=0)
+        sample_ranges = np.concatenate(sample_ranges, axis=0)
+        n_labels = sample_preds.shape[-1]
+        video_dict = {}
+        for video in sample_names:
+            if video in video_dict:
+                continue
+            mask = sample_names == video
+            video_ranges, video_preds = sample_ranges[mask], sample_preds[mask]
+            max_len = max(r[-1] for r in video_ranges)
+            arr = np.zeros((max_len, n_labels))
+            min_f, max_f = 0, 0
+            for (start, end), pred in zip(video_ranges, video_preds):
+                arr[start:end, :] = pred
+                min_f, max_f = min(min_f, start), max(max_f, end)
+            assert (min_f == 0) and (max_f == max_len)
+            video_dict[video] = pd.DataFrame(data=arr, columns=self.label_name)
+        return video_dict
+
     def test(self, input_video):
         import pandas as pd
         video_name = os.path.basename(input_video).split('.')[0]

@@ -92,3 +92,19 @@ def test_lanes_on_several_streams_are_bit_identical(tester):
             b = tester.hot.forward_lanes((frames,), lengths, lanes, from_u8=True)
             torch.cuda.synchronize()
             assert torch.equal(a, b)
+
+
+def test_reference_style_dataloader_loop_matches_fused_path(tester, oracle):
+    """Tester.test_on_dataloader (windowed input, api/tester.py:76-121) == the fused de-duplicated pipeline."""
+    n = 100
+    clip = synthetic.make_clip_u8(80, n)
+    gray, rgb = synthetic.preprocess_host(clip)
+    feats = tester.resnet50_extractor.get_vec(torch.from_numpy(rgb).to(tester.device)).cpu().numpy()
+    ranges = sampler.snippet_ranges(n)
+    batch = (np.stack([gray[sampler.window_ids(s, e, n)] for s, e in ranges]),        # [2,64,13,48,48]
+             np.stack([feats[s:e] for s, e in ranges]), None, np.array(ranges), np.array(["v"] * len(ranges)))
+    res = tester.test_on_dataloader([batch])
+    fused = tester.test_frames([clip], names=["v"])
+    assert res["v"].shape == (n, 2)
+    # same kernels; only the pyramid de-duplication differs, which is exact per frame
+    np.testing.assert_array_equal(res["v"].values, fused["v"].values)
