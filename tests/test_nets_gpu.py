@@ -46,6 +46,10 @@ CASES = [
     (2, 12, 12, 88, 128, 3, 1, 1, 1, 2),     # K = 792
     (3, 20, 20, 64, 64, 3, 1, 1, 1, 4),      # 256x64 tiles (4x1 waves), M = 1200: ragged last tile
     (1, 23, 23, 4, 64, 7, 2, 3, 1, 4),       # stem-like on 256x64
+    (1, 5, 5, 8, 16, 1, 1, 0, 1, 0),         # K = 8 < one chunk: k-quads beyond K are range-checked to zero
+    (1, 1, 1, 256, 8, 1, 1, 0, 0, 0),        # a single output row (M = 1)
+    (2, 6, 6, 16, 32, 3, 1, 1, 1, 0),        # one 16-channel slice
+    (1, 9, 9, 32, 48, 5, 1, 2, 0, 1),        # 5x5 taps, pad 2
 ]
 
 
@@ -195,3 +199,14 @@ def test_resnet50_full_batch_properties(resnet, dev):
     assert torch.isfinite(a).all() and torch.equal(a, b)
     sub = resnet.get_vec(x[10:14].contiguous())
     assert (sub - a[10:14]).abs().max() / a.abs().max() < 1e-5
+
+
+def test_zero_sized_calls_are_noops(pkg, dev):
+    from mimamo_net_amd.phase_difference_extractor import Phase_Difference_Extractor
+    from mimamo_net_amd.mimamo_net import Two_Stream_RNN
+    pde = Phase_Difference_Extractor(4, 2, 2, [1, 2])
+    c1, c2 = pde.build_pyramid(torch.zeros(0, 13, 48, 48, device=dev))
+    assert tuple(c1.shape) == (0, 2, 13, 48, 48, 2) and tuple(pde.extract(c1).shape) == (0, 2, 12, 48, 48)
+    m = Two_Stream_RNN().load_state_dict(weights.make_two_stream_state_dict(seed=3)).eval().to(dev)
+    y = m([torch.zeros(0, 4, 24, 48, 48, device=dev), torch.zeros(0, 4, 24, 24, 24, device=dev)], torch.zeros(0, 4, 2048, device=dev))
+    assert tuple(y.shape) == (0, 4, 2)
