@@ -10,17 +10,20 @@
 // reference's fp32 convs only by summation order (the 1e-4 output tolerance of north_star rules
 // out bf16/fp16 operands).
 //
-// GEMM view:  out[m][n] = sum_k A[m][k] * Wt[n][k],  m = (b, ho, wo),  n = cout,  k = (r, s, c)
+// GEMM view:  out[m][n] = sum_k A[m][k] * Wt[n][k],  m = (b, ho, wo),  n = cout,  k = (r, s, c) or, for
+//   multi-tap kernels with Cin % 16 == 0, the slice-major order (c/16, r, s, c%16) (see `korder` below);
 //   activations NHWC (channel stride/offset allow channel-sliced reads and concat-writes),
 //   weights packed [Cout][Kpad] with k contiguous (Kpad = K rounded up to 16, zero filled).
 // Workgroup = 256 threads = 4 waves (2x2, or 4x1 for the 256x64 tile); block tile BM x BN x 16; each wave
 // owns (BM/WGM)x(BN/WGN) as 32x32 MFMA sub-tiles.  Operand tiles go global -> LDS directly
-// (buffer_load ... lds, no VGPR staging, no ds_write), double buffered, one barrier per 16-deep chunk;
-// the 16-byte slots of each LDS row are XOR-swizzled so the ds_read_b128 fragment reads are
-// bank-conflict free without padding.  Inside a chunk lanes 0-31 take k = 0..7 and lanes 32-63 take
-// k = 8..15 (any k order is a valid contraction order), so one b128 read feeds four MFMAs.
+// (buffer_load ... lds from inline asm: no VGPR staging, no ds_write) into a 3-deep LDS ring tracked with
+// counted `s_waitcnt vmcnt(N)`, one `s_barrier` per 16-deep chunk; the 16-byte slots of each LDS row are
+// XOR-swizzled so the ds_read_b128 fragment reads are bank-conflict free without padding.  Inside a chunk
+// lanes 0-31 take k = 0..7 and lanes 32-63 take k = 8..15 (any k order is a valid contraction order), so one
+// b128 read feeds four MFMAs.  Zero padding of every kind comes from the buffer descriptors' range check.
 // Epilogue (fused): + bias (BN folded on the host) [+ residual] [ReLU] [* post_scale + post_shift]
-// (BN placed after ReLU, mimamo_net.py:54-62,115-117), stored as 128-byte channel rows.
+// (BN placed after ReLU, mimamo_net.py:54-62,115-117); the accumulator tile is transposed through LDS so
+// bias/residual/output move as 16-byte accesses, 256 bytes per row.
 #include "mm_common.h"
 #include <cstdio>
 #include "conv.h"
@@ -28,13 +31,13 @@
 namespace mm {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int CBK = 16;   // k-chunk
 constexpr int CLD = 16;   // LDS row = one 16-float chunk; the four 16-byte slots of a row are XOR-swizzled
 
 // ABL: measurement-only instantiation whose loop stages can be switched off at run time (p.ablate bits:
-// 1 no global loads, 2 no LDS stores, 4 no barrier, 8 no fragment reads) to attribute time; results are wrong.
+// 1 no loads + no tap math, 128 no loads, 256 no tap math, 4 no barrier, 8 no fragment reads, 32/64 wave-priority
+// experiments) to attribute time; its results are wrong by construction.  Reached only through tile >= 16.
 // KMODE selects the tap iteration at compile time (straight-line VALU in the hot loop):
 //   0  k = (r,s,c), any Cin % 4 == 0 (stem: Cin = 4)      2  k = (r,s,c), Cin >= 16 (one wrap per chunk at most)
 //   1  slice-major k = (c/16, r, s, c%16), Cin % 16 == 0    3  1x1 kernel, pad 0: no taps, no border
