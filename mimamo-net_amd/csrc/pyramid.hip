@@ -27,7 +27,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int S = 48;        // frame side
 constexpr int LDD = 49;      // D as A/B operand: odd stride
-constexpr int NT = 256;      // threads per workgroup
+constexpr int NT = 256;      // threads per workgroup (512 measured slower: 0.62 vs 0.46 ms per 2048 frames)
 constexpr int NW = NT / 64;  // waves
 
 // global table offsets (floats)
