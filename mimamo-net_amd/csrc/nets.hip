@@ -186,7 +186,7 @@ int mm_conv2d_nhwc(const float* in, const float* w, const float* bias, const flo
                    int relu, int tile, int korder, void* stream) {
     using namespace mm;
     if (!in || !w || !out || B < 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || kh <= 0 || kw <= 0 || stride <= 0 ||
-        pad < 0 || tile < 0 || tile > 1023)
+        pad < 0 || tile < 0 || tile > 2047)
         return MM_ERR_INVALID_ARG;
     if ((post_scale == nullptr) != (post_shift == nullptr)) return MM_ERR_INVALID_ARG;
     ConvParams p;

@@ -51,6 +51,9 @@ class HotPath(object):
         independent_clips=True: every video is exactly one snippet of `length` frames, so each GRU call has
         seq_len 1 and the calls are batched into one (identical results: GRU batch elements are independent)."""
         J = plan["ids"].shape[0]
+        if independent_clips and any(len(v["ranges"]) != 1 for v in plan["videos"]):
+            raise ValueError("independent_clips=True needs single-snippet videos: a multi-snippet video's GRU runs over "
+                             "its snippets (api/mimamo_net.py:119,139) and must get its own call")
         p0, cat = self.pde.phase_diff_frames(gray, plan["ids"], nhwc=True, out1_cstride=88, out1_coffset=64)
         feats = self.resnet.get_vec(rgb, channels_last4=(rgb.dim() == 4 and rgb.shape[-1] == 4))  # [N,2048], per unique frame
         rgb_rows = feats if J == feats.shape[0] and independent_clips else feats.index_select(0, plan["rows"])
