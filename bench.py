@@ -101,6 +101,7 @@ def main():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL; gloo only for "
                     "plumbing tests of the multi-process path on a single GPU, together with --same-device)")
     ap.add_argument("--same-device", action="store_true", help="testing only: every rank uses cuda:0")
+    ap.add_argument("--no-winograd", action="store_true", help="run every 3x3 layer in the direct implicit-GEMM form")
     ap.add_argument("--lanes", type=int, default=2, help="HIP streams the clips of a step are spread over (1 = single stream)")
     ap.add_argument("--from-u8", action="store_true",
                     help="start every step from the raw boundary (uint8 112x112x3 aligned faces in HBM): adds the "
@@ -128,6 +129,8 @@ def main():
     head_sd = weights.make_two_stream_state_dict(seed=0)
     resnet_sd = weights.make_resnet50_state_dict(seed=0)
     hot = HotPath(head_sd, resnet_sd, device)
+    if args.no_winograd:
+        hot.resnet.set_winograd(False)
     gray, rgb = make_inputs(args.clips, rank, device)
     plan = hot.plan([FRAMES_PER_CLIP] * args.clips)
     n_frames = args.clips * FRAMES_PER_CLIP

@@ -22,6 +22,8 @@ struct ConvParams {
     int force_tile;  // 0 auto, 1 = 128x128, 2 = 128x64, 3 = 64x64, 4 = 256x64, 16+bits = ablation build (measurement only)
     int ablate;
     int Cin_real;    // un-padded input channels (FLOP accounting only; 0 = Cin)
+    int batch;       // >1: `batch` independent problems of this shape in one launch (0/1 = single)
+    int64_t in_bstride, w_bstride, out_bstride;   // element strides between the problems of a batch
     int M, tiles_m, tiles_n;  // filled by conv_forward
 };
 
@@ -33,6 +35,12 @@ int nchw_to_nhwc(const float* in, float* out, int64_t N, int C, int HW, int cstr
 int maxpool3x3s2(const float* in, float* out, int64_t N, int H, int W, int C, int Ho, int Wo, hipStream_t s);
 // global average pool over HW (AvgPool2d(k=HW side)); optional ReLU afterwards
 int avgpool_hw(const float* in, float* out, int64_t N, int HW, int C, int out_cstride, int out_coff, int relu, hipStream_t s);
+// Winograd F(2x2, 3x3) transforms around a batched GEMM (winograd.hip)
+//   input : x NHWC [B,H,W,C] (pad 1)            -> V [16][B*TH*TW][C],  TH = ceil(H/2), TW = ceil(W/2)
+//   output: M [16][B*TH*TW][Cout] + bias, ReLU  -> y NHWC [B,H,W,Cout]
+int wino_input_transform(const float* x, float* V, int B, int H, int W, int C, hipStream_t s);
+int wino_output_transform(const float* M, const float* bias, float* y, int B, int H, int W, int Cout, int relu, hipStream_t s);
+
 // one GRU time step for a batch of Bt rows (PyTorch gate order r,z,n):
 //   gi [Bt, gi_stride] (+gi_off) = W_ih x + b_ih ; gh [Bt, 3H] = W_hh h + b_hh (or null with bhh => h == 0)
 //   h_out[b, out_stride*b + out_off + j] = (1-z)*n + z*h_prev

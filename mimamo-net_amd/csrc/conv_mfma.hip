@@ -73,6 +73,13 @@ conv_mfma_kernel(const ConvParams p) {
         const int q = nblk >> 3, r = nblk & 7;
         logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
     }
+    // batched launch (Winograd: 16 independent GEMMs of one shape): the grid holds `batch` copies of the tile grid
+    const int per_batch = p.tiles_m * p.tiles_n;
+    const int bz = logical / per_batch;
+    logical -= bz * per_batch;
+    const float* __restrict__ in_b = p.in + (int64_t)bz * p.in_bstride;
+    const float* __restrict__ w_b = p.w + (int64_t)bz * p.w_bstride;
+    float* __restrict__ out_b = p.out + (int64_t)bz * p.out_bstride;
     const int tile_m = logical / p.tiles_n, tile_n = logical - tile_m * p.tiles_n;
     const int m_base = tile_m * BM, n_base = tile_n * BN;
 
@@ -86,9 +93,9 @@ conv_mfma_kernel(const ConvParams p) {
     const int64_t rem_elems = ((int64_t)p.B - img0) * img_elems;
     const unsigned a_bytes = rem_elems * 4 > 0xFFFFF000ll ? 0xFFFFF000u : (unsigned)(rem_elems * 4);
     const __amdgpu_buffer_rsrc_t rsrc_a =
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.in) + img0 * img_elems, 0, a_bytes, 0x00020000);
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(in_b) + img0 * img_elems, 0, a_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsrc_b =
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.w), 0, (unsigned)((int64_t)p.Cout * p.Kpad * 4), 0x00020000);
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(w_b), 0, (unsigned)((int64_t)p.Cout * p.Kpad * 4), 0x00020000);
     constexpr unsigned OOB = 0xFFFFFFFFu;
 
     // DMA lane mapping: wave w, instruction `it` covers rows (it*4 + w)*16 .. +15; lane l -> row + (l >> 2), slot l & 3
@@ -329,7 +336,7 @@ conv_mfma_kernel(const ConvParams p) {
                 if (p.post_scale) {
                     o.x = o.x * ps4.x + pt4.x; o.y = o.y * ps4.y + pt4.y; o.z = o.z * ps4.z + pt4.z; o.w = o.w * ps4.w + pt4.w;
                 }
-                if (nok && m < p.M) *reinterpret_cast<float4*>(p.out + (int64_t)m * p.out_cstride + p.out_coff + n0) = o;
+                if (nok && m < p.M) *reinterpret_cast<float4*>(out_b + (int64_t)m * p.out_cstride + p.out_coff + n0) = o;
             }
             if (i + 1 < TM) __syncthreads();
         }
@@ -353,7 +360,7 @@ conv_mfma_kernel(const ConvParams p) {
                     if (p.res) v += p.res[(int64_t)m * p.res_cstride + p.res_coff + n];
                     if (p.relu) v = fmaxf(v, 0.f);
                     if (p.post_scale) v = v * ps + pt;
-                    p.out[(int64_t)m * p.out_cstride + p.out_coff + n] = v;
+                    out_b[(int64_t)m * p.out_cstride + p.out_coff + n] = v;
                 }
             }
         }
@@ -364,12 +371,13 @@ template <int BM, int BN, int WGM, int WGN, int KMODE, bool ABL = false>
 static int launch_km(ConvParams p, hipStream_t stream) {
     p.tiles_m = (p.M + BM - 1) / BM;
     p.tiles_n = (p.Cout + BN - 1) / BN;
-    const int64_t blocks = (int64_t)p.tiles_m * p.tiles_n;
+    if (p.batch < 1) p.batch = 1;
+    const int64_t blocks = (int64_t)p.tiles_m * p.tiles_n * p.batch;
     if (blocks <= 0 || blocks > 0x7fffffff) return MM_ERR_INVALID_ARG;
     if (prof_enabled()) {
         char tag[64];
-        snprintf(tag, sizeof(tag), "M=%d K=%d N=%d k%d s%d t%dx%d", p.M, p.K, p.Cout, p.kh, p.stride, BM, BN);
-        prof_before(0, 2.0 * (double)p.M * (double)(p.kh * p.kw * p.Cin_real) * (double)p.Cout, stream, tag);
+        snprintf(tag, sizeof(tag), "M=%d K=%d N=%d k%d s%d t%dx%d b%d", p.M, p.K, p.Cout, p.kh, p.stride, BM, BN, p.batch);
+        prof_before(0, 2.0 * (double)p.M * (double)(p.kh * p.kw * p.Cin_real) * (double)p.Cout * (double)p.batch, stream, tag);
     }
     hipLaunchKernelGGL((conv_mfma_kernel<BM, BN, WGM, WGN, KMODE, ABL>), dim3((unsigned)blocks), dim3(256), 0, stream, p);
     prof_after(0, stream);

@@ -17,6 +17,7 @@ namespace mm {
 
 struct Layer {
     float *w = nullptr, *bias = nullptr, *ps = nullptr, *pt = nullptr;
+    float* wino_u = nullptr;  // [16][cout][cin] Winograd-domain weights (stride-1 3x3 layers with cin >= 128), or null
     int cin = 0, cin_p = 0, cout = 0, k = 1, stride = 1, pad = 0, K = 0, Kpad = 0, relu = 0, korder = 0;
 };
 
@@ -45,7 +46,7 @@ struct BN {
 // Build one conv/linear layer from host tensors.  w: [cout][cin][k][k] (OIHW), bias may be null.
 // fold: BN directly after the conv (scale into the weights).  post: BN after the ReLU.
 static int make_layer(DeviceArena& A, Layer& L, const float* w, const float* bias, int cout, int cin, int k, int stride,
-                      int pad, int relu, const BN* fold, const BN* post, float eps) {
+                      int pad, int relu, const BN* fold, const BN* post, float eps, bool wino = false) {
     L.cin = cin;
     L.cin_p = (cin + 3) / 4 * 4;
     L.cout = cout;
@@ -75,6 +76,25 @@ static int make_layer(DeviceArena& A, Layer& L, const float* w, const float* bia
     }
     int rc = A.upload(hw, &L.w);
     if (rc == MM_OK) rc = A.upload(hb, &L.bias);
+    if (rc == MM_OK && wino && k == 3 && stride == 1 && pad == 1 && cin % 16 == 0 && cin >= 128 && cout % 4 == 0) {
+        // U = G g G^T, G = [1 0 0; .5 .5 .5; .5 -.5 .5; 0 0 1], on the BN-folded filter, float64 -> fp32
+        static const double G[4][3] = {{1, 0, 0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0, 0, 1}};
+        std::vector<float> hu((size_t)16 * cout * cin);
+        for (int o = 0; o < cout; ++o) {
+            const double sc = fold ? (double)fold->gamma[o] / std::sqrt((double)fold->var[o] + (double)eps) : 1.0;
+            for (int c = 0; c < cin; ++c) {
+                double g[3][3], t[4][3];
+                for (int r = 0; r < 3; ++r)
+                    for (int q = 0; q < 3; ++q) g[r][q] = (double)w[(((size_t)o * cin + c) * 3 + r) * 3 + q] * sc;
+                for (int i = 0; i < 4; ++i)
+                    for (int q = 0; q < 3; ++q) t[i][q] = G[i][0] * g[0][q] + G[i][1] * g[1][q] + G[i][2] * g[2][q];
+                for (int i = 0; i < 4; ++i)
+                    for (int j = 0; j < 4; ++j)
+                        hu[((size_t)(i * 4 + j) * cout + o) * cin + c] = (float)(t[i][0] * G[j][0] + t[i][1] * G[j][1] + t[i][2] * G[j][2]);
+            }
+        }
+        rc = A.upload(hu, &L.wino_u);
+    }
     if (rc == MM_OK && post) {
         std::vector<float> ps(cout), pt(cout);
         for (int o = 0; o < cout; ++o) {
@@ -106,6 +126,25 @@ static int run_layer(const Layer& L, const float* in, int B, int H, int W, int i
     return conv_forward(p, s);
 }
 
+// Stride-1 3x3 layer through Winograd F(2x2,3x3): input transform, ONE batched GEMM launch (16 problems), output
+// transform with the fused bias/ReLU.  V and M are caller-provided scratch of 16*B*ceil(H/2)*ceil(W/2)*C floats.
+static int run_layer_wino(const Layer& L, const float* in, int B, int H, int W, float* out, float* V, float* M, hipStream_t s) {
+    const int TH = (H + 1) / 2, TW = (W + 1) / 2;
+    const int64_t ntile = (int64_t)B * TH * TW;
+    if (ntile > 0x7fffffff) return MM_ERR_INVALID_ARG;
+    int rc = wino_input_transform(in, V, B, H, W, L.cin, s);
+    if (rc != MM_OK) return rc;
+    ConvParams p;
+    std::memset(&p, 0, sizeof(p));
+    p.in = V; p.w = L.wino_u; p.out = M;
+    p.B = (int)ntile; p.H = 1; p.W = 1; p.Cin = L.cin; p.in_cstride = L.cin; p.Ho = 1; p.Wo = 1;
+    p.Cout = L.cout; p.out_cstride = L.cout; p.kh = 1; p.kw = 1; p.stride = 1; p.K = L.cin; p.Kpad = L.cin; p.Cin_real = L.cin;
+    p.batch = 16; p.in_bstride = ntile * L.cin; p.w_bstride = (int64_t)L.cout * L.cin; p.out_bstride = ntile * L.cout;
+    rc = conv_forward(p, s);
+    if (rc != MM_OK) return rc;
+    return wino_output_transform(M, L.bias, out, B, H, W, L.cout, L.relu, s);
+}
+
 struct Bump {
     char* base;
     int64_t off = 0, cap;
@@ -134,6 +173,7 @@ struct mm_resnet50 {
     mm::Layer stem;
     std::vector<mm::Bottleneck> blocks;
     int ceil_mode;
+    int winograd;  // use the Winograd path for the layers that have Winograd-domain weights
 };
 
 struct mm_head {
@@ -217,12 +257,13 @@ int mm_resnet50_create(mm_resnet50_t** out, const float* blob, int64_t n_floats,
     h->ceil_mode = maxpool_ceil_mode;
     const float* p = blob;
     int rc = MM_OK;
+    h->winograd = 1;
     auto conv_bn = [&](Layer& L, int cout, int cin, int k, int stride, int pad, int relu) {
         const float* w = p;
         p += (int64_t)cout * cin * k * k;
         BN bn{p, p + cout, p + 2 * cout, p + 3 * cout};
         p += 4 * cout;
-        if (rc == MM_OK) rc = make_layer(h->arena, L, w, nullptr, cout, cin, k, stride, pad, relu, &bn, nullptr, bn_eps);
+        if (rc == MM_OK) rc = make_layer(h->arena, L, w, nullptr, cout, cin, k, stride, pad, relu, &bn, nullptr, bn_eps, true);
     };
     conv_bn(h->stem, 64, 3, 7, 2, 3, 1);
     int cin = 64;
@@ -258,7 +299,13 @@ int mm_resnet50_destroy(mm_resnet50_t* h) {
 int64_t mm_resnet50_workspace_bytes(mm_resnet50_t* h, int64_t batch) {
     using namespace mm;
     if (!h || batch < 0) return MM_ERR_INVALID_ARG;
-    return Bump::size_of(batch * kRsIn4) + 3 * Bump::size_of(batch * kRsBig) + 2 * Bump::size_of(batch * kRsMid);
+    return Bump::size_of(batch * kRsIn4) + 3 * Bump::size_of(batch * kRsBig) + 4 * Bump::size_of(batch * kRsMid);
+}
+
+int mm_resnet50_set_winograd(mm_resnet50_t* h, int enable) {
+    if (!h) return MM_ERR_INVALID_ARG;
+    h->winograd = enable ? 1 : 0;
+    return MM_OK;
 }
 
 int mm_resnet50_forward(mm_resnet50_t* h, const float* images, int nchw, int64_t batch, float* out, void* workspace,
@@ -275,6 +322,8 @@ int mm_resnet50_forward(mm_resnet50_t* h, const float* images, int nchw, int64_t
     float* big[3] = {ws.take(batch * kRsBig), ws.take(batch * kRsBig), ws.take(batch * kRsBig)};
     float* y1 = ws.take(batch * kRsMid);
     float* y2 = ws.take(batch * kRsMid);
+    float* wv = ws.take(batch * kRsMid);   // Winograd V: 16 * tiles * C floats per frame <= 56*56*128 for conv3_x..conv5_x
+    float* wm = ws.take(batch * kRsMid);   // Winograd M
     int rc;
     const float* x0 = images;
     if (nchw) {
@@ -312,7 +361,13 @@ int mm_resnet50_forward(mm_resnet50_t* h, const float* images, int nchw, int64_t
         }
         rc = run_layer(Bk.reduce, x, B, H, W, C, 0, y1, Bk.reduce.cout, 0, nullptr, 0, s, &H1, &W1);
         if (rc != MM_OK) return rc;
-        rc = run_layer(Bk.conv3, y1, B, H1, W1, Bk.reduce.cout, 0, y2, Bk.conv3.cout, 0, nullptr, 0, s, &H2, &W2);
+        if (h->winograd && Bk.conv3.wino_u &&
+            (int64_t)16 * ((H1 + 1) / 2) * ((W1 + 1) / 2) * Bk.conv3.cin <= kRsMid) {
+            rc = run_layer_wino(Bk.conv3, y1, B, H1, W1, y2, wv, wm, s);
+            H2 = H1; W2 = W1;
+        } else {
+            rc = run_layer(Bk.conv3, y1, B, H1, W1, Bk.reduce.cout, 0, y2, Bk.conv3.cout, 0, nullptr, 0, s, &H2, &W2);
+        }
         if (rc != MM_OK) return rc;
         rc = run_layer(Bk.increase, y2, B, H2, W2, Bk.conv3.cout, 0, o, Bk.increase.cout, 0, resid, Bk.increase.cout, s, &H3, &W3);
         if (rc != MM_OK) return rc;

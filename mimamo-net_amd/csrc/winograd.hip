@@ -1,0 +1,125 @@
+// Winograd F(2x2, 3x3) for the stride-1 3x3 convolutions of the ResNet50 trunk (conv3_x..conv5_x, 13 layers,
+// 38 % of the network's FLOPs): 2.25x fewer multiply-adds than the direct form for the same result up to fp32
+// rounding (input/output transforms use only additions; the weight transform is done once on the host in float64).
+//   V = B^T d B  per 4x4 input patch (stride 2, pad 1)     -- this file, memory-bound
+//   M_xi = V_xi * U_xi, xi = 0..15                         -- one BATCHED launch of the fp32 MFMA GEMM engine
+//   Y = A^T M A + bias, ReLU  per 2x2 output patch         -- this file, memory-bound
+// The reference computes these layers with torch's direct fp32 conv (third-party ResNet50, api/resnet50_extractor.py:
+// 74-83); parity is checked against the oracle's direct convolution.
+#include "conv.h"
+
+namespace mm {
+
+// one thread: one tile, four consecutive channels
+__global__ void __launch_bounds__(256)
+wino_in_kernel(const float* __restrict__ x, float* __restrict__ V, int B, int H, int W, int C4, int TH, int TW, int64_t total) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int c4 = (int)(i % C4);
+    const int64_t tile = i / C4;
+    const int tx = (int)(tile % TW);
+    const int ty = (int)((tile / TW) % TH);
+    const int64_t b = tile / ((int64_t)TW * TH);
+    const float4* src = reinterpret_cast<const float4*>(x);
+    float4 d[4][4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int hy = 2 * ty - 1 + r;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int wx = 2 * tx - 1 + q;
+            const bool ok = (unsigned)hy < (unsigned)H && (unsigned)wx < (unsigned)W;
+            d[r][q] = ok ? src[((b * H + hy) * W + wx) * C4 + c4] : float4{0.f, 0.f, 0.f, 0.f};
+        }
+    }
+    // B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1]:  t = B^T d (rows), V = t B (columns)
+    auto sub = [](float4 a, float4 b) { return float4{a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w}; };
+    auto add = [](float4 a, float4 b) { return float4{a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w}; };
+    float4 t[4][4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        t[0][q] = sub(d[0][q], d[2][q]);
+        t[1][q] = add(d[1][q], d[2][q]);
+        t[2][q] = sub(d[2][q], d[1][q]);
+        t[3][q] = sub(d[1][q], d[3][q]);
+    }
+    float4* dst = reinterpret_cast<float4*>(V);
+    const int64_t ntile = (int64_t)B * TH * TW;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const float4 v0 = sub(t[r][0], t[r][2]), v1 = add(t[r][1], t[r][2]), v2 = sub(t[r][2], t[r][1]), v3 = sub(t[r][1], t[r][3]);
+        dst[((int64_t)(r * 4 + 0) * ntile + tile) * C4 + c4] = v0;
+        dst[((int64_t)(r * 4 + 1) * ntile + tile) * C4 + c4] = v1;
+        dst[((int64_t)(r * 4 + 2) * ntile + tile) * C4 + c4] = v2;
+        dst[((int64_t)(r * 4 + 3) * ntile + tile) * C4 + c4] = v3;
+    }
+}
+
+__global__ void __launch_bounds__(256)
+wino_out_kernel(const float* __restrict__ M, const float* __restrict__ bias, float* __restrict__ y, int B, int H, int W, int C4,
+                int TH, int TW, int relu, int64_t total) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int c4 = (int)(i % C4);
+    const int64_t tile = i / C4;
+    const int tx = (int)(tile % TW);
+    const int ty = (int)((tile / TW) % TH);
+    const int64_t b = tile / ((int64_t)TW * TH);
+    const int64_t ntile = (int64_t)B * TH * TW;
+    const float4* src = reinterpret_cast<const float4*>(M);
+    float4 m[4][4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) m[r][q] = src[((int64_t)(r * 4 + q) * ntile + tile) * C4 + c4];
+    // A^T = [1 1 1 0; 0 1 -1 -1]
+    auto add3 = [](float4 a, float4 b, float4 c) { return float4{a.x + b.x + c.x, a.y + b.y + c.y, a.z + b.z + c.z, a.w + b.w + c.w}; };
+    auto sub3 = [](float4 a, float4 b, float4 c) { return float4{a.x - b.x - c.x, a.y - b.y - c.y, a.z - b.z - c.z, a.w - b.w - c.w}; };
+    float4 t[2][4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        t[0][q] = add3(m[0][q], m[1][q], m[2][q]);
+        t[1][q] = sub3(m[1][q], m[2][q], m[3][q]);
+    }
+    const float4 bs = bias ? reinterpret_cast<const float4*>(bias)[c4] : float4{0.f, 0.f, 0.f, 0.f};
+    float4* dst = reinterpret_cast<float4*>(y);
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        float4 o[2];
+        o[0] = add3(t[r][0], t[r][1], t[r][2]);
+        o[1] = sub3(t[r][1], t[r][2], t[r][3]);
+        const int hy = 2 * ty + r;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int wx = 2 * tx + q;
+            if (hy < H && wx < W) {
+                float4 v = {o[q].x + bs.x, o[q].y + bs.y, o[q].z + bs.z, o[q].w + bs.w};
+                if (relu) v = float4{fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f)};
+                dst[((b * H + hy) * W + wx) * C4 + c4] = v;
+            }
+        }
+    }
+}
+
+int wino_input_transform(const float* x, float* V, int B, int H, int W, int C, hipStream_t s) {
+    if (C % 4) return MM_ERR_INVALID_ARG;
+    const int TH = (H + 1) / 2, TW = (W + 1) / 2;
+    const int64_t total = (int64_t)B * TH * TW * (C / 4);
+    if (total <= 0) return MM_OK;
+    hipLaunchKernelGGL(wino_in_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, x, V, B, H, W, C / 4, TH, TW, total);
+    MM_LAUNCH_CHECK();
+    return MM_OK;
+}
+
+int wino_output_transform(const float* M, const float* bias, float* y, int B, int H, int W, int Cout, int relu, hipStream_t s) {
+    if (Cout % 4) return MM_ERR_INVALID_ARG;
+    const int TH = (H + 1) / 2, TW = (W + 1) / 2;
+    const int64_t total = (int64_t)B * TH * TW * (Cout / 4);
+    if (total <= 0) return MM_OK;
+    hipLaunchKernelGGL(wino_out_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, M, bias, y, B, H, W, Cout / 4, TH, TW,
+                       relu, total);
+    MM_LAUNCH_CHECK();
+    return MM_OK;
+}
+
+}  // namespace mm

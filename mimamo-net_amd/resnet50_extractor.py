@@ -43,6 +43,10 @@ class Resnet50_Extractor(object):
         self._handle = h
         self._ws = {}   # per-stream workspaces: the handle itself is stateless, so lanes on different streams may share it
 
+    def set_winograd(self, enable=True):
+        """Winograd F(2x2,3x3) for the stride-1 3x3 layers of conv3_x..conv5_x (default on); False = direct form."""
+        _lib.check(_lib.lib().mm_resnet50_set_winograd(self._handle, 1 if enable else 0), "mm_resnet50_set_winograd")
+
     def close(self):
         if getattr(self, "_handle", None) is not None:
             _lib.lib().mm_resnet50_destroy(self._handle)

@@ -191,6 +191,26 @@ def test_resnet50_pool5_vs_oracle(resnet, oracle, dev):
     np.testing.assert_array_equal(got4, got)
 
 
+def test_resnet50_winograd_and_direct_paths_agree(resnet, oracle, dev):
+    """conv3_x..conv5_x 3x3 layers: Winograd F(2x2,3x3) (default) vs the direct implicit-GEMM form vs the oracle."""
+    x = _images(2, 7)
+    want = oracle.resnet50_pool5(weights.make_resnet50_state_dict(seed=0), x)
+    xt = torch.from_numpy(x).to(dev)
+    scale = np.abs(want).max()
+    try:
+        resnet.set_winograd(True)
+        a = resnet.get_vec(xt).cpu().numpy()
+        resnet.set_winograd(False)
+        b = resnet.get_vec(xt).cpu().numpy()
+    finally:
+        resnet.set_winograd(True)
+    assert not np.array_equal(a, b)                      # two different algorithms really ran
+    for got in (a, b):
+        assert np.abs(got - want).max() / scale < POOL5_RTOL * 10
+        assert np.abs(got - want).mean() / scale < POOL5_RTOL
+    assert np.abs(a - b).max() / scale < POOL5_RTOL * 10
+
+
 def test_resnet50_full_batch_properties(resnet, dev):
     """BASELINE config 3 size (batch 64): finite, deterministic, batch-invariant."""
     x = torch.from_numpy(_images(64, 2)).to(dev)
