@@ -181,9 +181,9 @@ def main():
 
     # ---- roofline leg: hipEvent-timed launches of one more step (same stream), by kernel category
     L = _lib.lib()
-    ms = (ctypes.c_double * 3)()
-    work = (ctypes.c_double * 3)()
-    launches = (ctypes.c_int64 * 3)()
+    ms = (ctypes.c_double * 4)()
+    work = (ctypes.c_double * 4)()
+    launches = (ctypes.c_int64 * 4)()
     with torch.no_grad():
         L.mm_profile_begin()
         # single stream for this leg: with several lanes in flight a kernel's event bracket also counts the time it
@@ -240,7 +240,13 @@ def main():
                      "frac": conv_tflops / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic,
                      "traffic_note": "HBM bytes per step over all conv launches, rocprofv3 PMC (2*FETCH_SIZE + WRITE_SIZE)*1024, "
                                      "from profiles/ (not live)" if traffic else None,
-                     "flops_per_step": work[0], "ms_per_step": ms[0], "launches_per_step": int(launches[0])},
+                     "flops_per_step": work[0], "ms_per_step": ms[0], "launches_per_step": int(launches[0]),
+                     "note": "flops = executed on the matrix cores; with Winograd F(2x2,3x3) on the conv3_x..conv5_x 3x3 layers "
+                             "that is less than the direct-form count (algorithmic_direct_flops_per_step = 8.108 GFLOP/frame)",
+                     "algorithmic_direct_flops_per_step": 8.108e9 * n_frames,
+                     "winograd": (not args.no_winograd),
+                     "winograd_transforms": {"ms_per_step": ms[3], "bytes_per_step": work[3], "launches_per_step": int(launches[3]),
+                                             "GB_per_s": (work[3] / (ms[3] * 1e-3) / 1e9) if ms[3] > 0 else None}},
         "roofline_phase": {"bound": "hbm", "kernel": "pyramid_kernel + phase_window_kernel<48|24>",
                            "achieved": phase_gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": phase_gbs / PEAK_HBM_GBS,
                            "traffic": ptraffic, "bytes_per_step": work[1] + work[2], "ms_per_step": phase_ms,

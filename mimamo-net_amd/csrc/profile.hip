@@ -53,7 +53,7 @@ int mm_profile_begin(void) {
 }
 
 // ms[c], work[c], launches[c] for c in [0, MM_PROF_CATEGORIES): 0 = conv/GEMM engine (work = algorithmic
-// FLOPs), 1 = pyramid, 2 = phase window (work = algorithmic HBM bytes).
+// FLOPs), 1 = pyramid, 2 = phase window (work = algorithmic HBM bytes), 3 = Winograd transforms (bytes moved).
 int mm_profile_end(double* ms, double* work, int64_t* launches) {
     if (!ms || !work || !launches) return MM_ERR_INVALID_ARG;
     mm::g_prof_on = false;

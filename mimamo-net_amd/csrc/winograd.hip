@@ -106,7 +106,9 @@ int wino_input_transform(const float* x, float* V, int B, int H, int W, int C, h
     const int TH = (H + 1) / 2, TW = (W + 1) / 2;
     const int64_t total = (int64_t)B * TH * TW * (C / 4);
     if (total <= 0) return MM_OK;
+    prof_before(3, (double)B * C * 4.0 * ((double)H * W + 16.0 * TH * TW), s);   // read x once, write 16 planes
     hipLaunchKernelGGL(wino_in_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, x, V, B, H, W, C / 4, TH, TW, total);
+    prof_after(3, s);
     MM_LAUNCH_CHECK();
     return MM_OK;
 }
@@ -116,8 +118,10 @@ int wino_output_transform(const float* M, const float* bias, float* y, int B, in
     const int TH = (H + 1) / 2, TW = (W + 1) / 2;
     const int64_t total = (int64_t)B * TH * TW * (Cout / 4);
     if (total <= 0) return MM_OK;
+    prof_before(3, (double)B * Cout * 4.0 * ((double)H * W + 16.0 * TH * TW), s);
     hipLaunchKernelGGL(wino_out_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, M, bias, y, B, H, W, Cout / 4, TH, TW,
                        relu, total);
+    prof_after(3, s);
     MM_LAUNCH_CHECK();
     return MM_OK;
 }
