@@ -102,6 +102,7 @@ def main():
                     "plumbing tests of the multi-process path on a single GPU, together with --same-device)")
     ap.add_argument("--same-device", action="store_true", help="testing only: every rank uses cuda:0")
     ap.add_argument("--no-winograd", action="store_true", help="run every 3x3 layer in the direct implicit-GEMM form")
+    ap.add_argument("--winograd", type=int, default=1, help="1 = default variant (F(4x4,3x3)), 2 = F(2x2,3x3), 4 = F(4x4,3x3)")
     ap.add_argument("--lanes", type=int, default=2, help="HIP streams the clips of a step are spread over (1 = single stream)")
     ap.add_argument("--from-u8", action="store_true",
                     help="start every step from the raw boundary (uint8 112x112x3 aligned faces in HBM): adds the "
@@ -129,8 +130,7 @@ def main():
     head_sd = weights.make_two_stream_state_dict(seed=0)
     resnet_sd = weights.make_resnet50_state_dict(seed=0)
     hot = HotPath(head_sd, resnet_sd, device)
-    if args.no_winograd:
-        hot.resnet.set_winograd(False)
+    hot.resnet.set_winograd(0 if args.no_winograd else args.winograd)
     gray, rgb = make_inputs(args.clips, rank, device)
     plan = hot.plan([FRAMES_PER_CLIP] * args.clips)
     n_frames = args.clips * FRAMES_PER_CLIP
@@ -241,10 +241,10 @@ def main():
                      "traffic_note": "HBM bytes per step over all conv launches, rocprofv3 PMC (2*FETCH_SIZE + WRITE_SIZE)*1024, "
                                      "from profiles/ (not live)" if traffic else None,
                      "flops_per_step": work[0], "ms_per_step": ms[0], "launches_per_step": int(launches[0]),
-                     "note": "flops = executed on the matrix cores; with Winograd F(2x2,3x3) on the conv3_x..conv5_x 3x3 layers "
+                     "note": "flops = executed on the matrix cores; with Winograd F(4x4,3x3) (or F(2x2,3x3)) on the conv3_x..conv5_x 3x3 layers "
                              "that is less than the direct-form count (algorithmic_direct_flops_per_step = 8.108 GFLOP/frame)",
                      "algorithmic_direct_flops_per_step": 8.108e9 * n_frames,
-                     "winograd": (not args.no_winograd),
+                     "winograd": (0 if args.no_winograd else {1: 4}.get(args.winograd, args.winograd)),
                      "winograd_transforms": {"ms_per_step": ms[3], "bytes_per_step": work[3], "launches_per_step": int(launches[3]),
                                              "GB_per_s": (work[3] / (ms[3] * 1e-3) / 1e9) if ms[3] > 0 else None}},
         "roofline_phase": {"bound": "hbm", "kernel": "pyramid_kernel + phase_window_kernel<48|24>",

@@ -138,8 +138,9 @@ int64_t mm_resnet50_blob_floats(void);
 int mm_resnet50_create(mm_resnet50_t** out, const float* host_blob, int64_t n_floats,
                        int stride_on_first_1x1, int maxpool_ceil_mode, float bn_eps);
 int mm_resnet50_destroy(mm_resnet50_t* h);
-/* The stride-1 3x3 layers of conv3_x..conv5_x run by default as Winograd F(2x2,3x3) (2.25x fewer multiply-adds, same
- * result up to fp32 rounding); enable = 0 switches every layer back to the direct implicit-GEMM form. */
+/* The stride-1 3x3 layers of conv3_x..conv5_x run by default as Winograd F(4x4,3x3) (4x fewer multiply-adds, same
+ * result up to fp32 rounding).  mode: 0 = every layer in the direct implicit-GEMM form, 2 = F(2x2,3x3), 4 = F(4x4,3x3),
+ * 1 = the default variant. */
 int mm_resnet50_set_winograd(mm_resnet50_t* h, int enable);
 int64_t mm_resnet50_workspace_bytes(mm_resnet50_t* h, int64_t batch);
 /* images: device f32, [batch,3,224,224] (nchw=1, the reference's layout) or channels-last padded to four

@@ -35,11 +35,11 @@ int nchw_to_nhwc(const float* in, float* out, int64_t N, int C, int HW, int cstr
 int maxpool3x3s2(const float* in, float* out, int64_t N, int H, int W, int C, int Ho, int Wo, hipStream_t s);
 // global average pool over HW (AvgPool2d(k=HW side)); optional ReLU afterwards
 int avgpool_hw(const float* in, float* out, int64_t N, int HW, int C, int out_cstride, int out_coff, int relu, hipStream_t s);
-// Winograd F(2x2, 3x3) transforms around a batched GEMM (winograd.hip)
-//   input : x NHWC [B,H,W,C] (pad 1)            -> V [16][B*TH*TW][C],  TH = ceil(H/2), TW = ceil(W/2)
-//   output: M [16][B*TH*TW][Cout] + bias, ReLU  -> y NHWC [B,H,W,Cout]
-int wino_input_transform(const float* x, float* V, int B, int H, int W, int C, hipStream_t s);
-int wino_output_transform(const float* M, const float* bias, float* y, int B, int H, int W, int Cout, int relu, hipStream_t s);
+// Winograd F(m x m, 3x3) transforms around a batched GEMM (winograd.hip), m = 2 or 4, a = m + 2
+//   input : x NHWC [B,H,W,C] (pad 1)             -> V [a*a][B*TH*TW][C],  TH = ceil(H/m), TW = ceil(W/m)
+//   output: M [a*a][B*TH*TW][Cout] + bias, ReLU  -> y NHWC [B,H,W,Cout]
+int wino_input_transform(const float* x, float* V, int B, int H, int W, int C, int m, hipStream_t s);
+int wino_output_transform(const float* M, const float* bias, float* y, int B, int H, int W, int Cout, int relu, int m, hipStream_t s);
 
 // one GRU time step for a batch of Bt rows (PyTorch gate order r,z,n):
 //   gi [Bt, gi_stride] (+gi_off) = W_ih x + b_ih ; gh [Bt, 3H] = W_hh h + b_hh (or null with bhh => h == 0)

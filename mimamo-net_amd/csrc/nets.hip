@@ -17,7 +17,8 @@ namespace mm {
 
 struct Layer {
     float *w = nullptr, *bias = nullptr, *ps = nullptr, *pt = nullptr;
-    float* wino_u = nullptr;  // [16][cout][cin] Winograd-domain weights (stride-1 3x3 layers with cin >= 128), or null
+    float* wino_u = nullptr;   // [16][cout][cin] F(2x2,3x3)-domain weights (stride-1 3x3 layers with cin >= 128), or null
+    float* wino_u4 = nullptr;  // [36][cout][cin] F(4x4,3x3)-domain weights
     int cin = 0, cin_p = 0, cout = 0, k = 1, stride = 1, pad = 0, K = 0, Kpad = 0, relu = 0, korder = 0;
 };
 
@@ -76,7 +77,7 @@ static int make_layer(DeviceArena& A, Layer& L, const float* w, const float* bia
     }
     int rc = A.upload(hw, &L.w);
     if (rc == MM_OK) rc = A.upload(hb, &L.bias);
-    if (rc == MM_OK && wino && k == 3 && stride == 1 && pad == 1 && cin % 16 == 0 && cin >= 128 && cout % 4 == 0) {
+    if (rc == MM_OK && wino && k == 3 && stride == 1 && pad == 1 && cin % 16 == 0 && cin >= 64 && cout % 4 == 0) {
         // U = G g G^T, G = [1 0 0; .5 .5 .5; .5 -.5 .5; 0 0 1], on the BN-folded filter, float64 -> fp32
         static const double G[4][3] = {{1, 0, 0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0, 0, 1}};
         std::vector<float> hu((size_t)16 * cout * cin);
@@ -94,6 +95,24 @@ static int make_layer(DeviceArena& A, Layer& L, const float* w, const float* bia
             }
         }
         rc = A.upload(hu, &L.wino_u);
+        // F(4x4,3x3): G = [1/4 0 0; -1/6 -1/6 -1/6; -1/6 1/6 -1/6; 1/24 1/12 1/6; 1/24 -1/12 1/6; 0 0 1]
+        static const double G4[6][3] = {{0.25, 0, 0}, {-1.0 / 6, -1.0 / 6, -1.0 / 6}, {-1.0 / 6, 1.0 / 6, -1.0 / 6},
+                                        {1.0 / 24, 1.0 / 12, 1.0 / 6}, {1.0 / 24, -1.0 / 12, 1.0 / 6}, {0, 0, 1}};
+        std::vector<float> hu4((size_t)36 * cout * cin);
+        for (int o = 0; o < cout && rc == MM_OK; ++o) {
+            const double sc = fold ? (double)fold->gamma[o] / std::sqrt((double)fold->var[o] + (double)eps) : 1.0;
+            for (int c = 0; c < cin; ++c) {
+                double g[3][3], t[6][3];
+                for (int r = 0; r < 3; ++r)
+                    for (int q = 0; q < 3; ++q) g[r][q] = (double)w[(((size_t)o * cin + c) * 3 + r) * 3 + q] * sc;
+                for (int i = 0; i < 6; ++i)
+                    for (int q = 0; q < 3; ++q) t[i][q] = G4[i][0] * g[0][q] + G4[i][1] * g[1][q] + G4[i][2] * g[2][q];
+                for (int i = 0; i < 6; ++i)
+                    for (int j = 0; j < 6; ++j)
+                        hu4[((size_t)(i * 6 + j) * cout + o) * cin + c] = (float)(t[i][0] * G4[j][0] + t[i][1] * G4[j][1] + t[i][2] * G4[j][2]);
+            }
+        }
+        if (rc == MM_OK) rc = A.upload(hu4, &L.wino_u4);
     }
     if (rc == MM_OK && post) {
         std::vector<float> ps(cout), pt(cout);
@@ -128,21 +147,21 @@ static int run_layer(const Layer& L, const float* in, int B, int H, int W, int i
 
 // Stride-1 3x3 layer through Winograd F(2x2,3x3): input transform, ONE batched GEMM launch (16 problems), output
 // transform with the fused bias/ReLU.  V and M are caller-provided scratch of 16*B*ceil(H/2)*ceil(W/2)*C floats.
-static int run_layer_wino(const Layer& L, const float* in, int B, int H, int W, float* out, float* V, float* M, hipStream_t s) {
-    const int TH = (H + 1) / 2, TW = (W + 1) / 2;
+static int run_layer_wino(const Layer& L, const float* in, int B, int H, int W, float* out, float* V, float* M, int m, hipStream_t s) {
+    const int TH = (H + m - 1) / m, TW = (W + m - 1) / m, npos = (m + 2) * (m + 2);
     const int64_t ntile = (int64_t)B * TH * TW;
     if (ntile > 0x7fffffff) return MM_ERR_INVALID_ARG;
-    int rc = wino_input_transform(in, V, B, H, W, L.cin, s);
+    int rc = wino_input_transform(in, V, B, H, W, L.cin, m, s);
     if (rc != MM_OK) return rc;
     ConvParams p;
     std::memset(&p, 0, sizeof(p));
-    p.in = V; p.w = L.wino_u; p.out = M;
+    p.in = V; p.w = m == 4 ? L.wino_u4 : L.wino_u; p.out = M;
     p.B = (int)ntile; p.H = 1; p.W = 1; p.Cin = L.cin; p.in_cstride = L.cin; p.Ho = 1; p.Wo = 1;
     p.Cout = L.cout; p.out_cstride = L.cout; p.kh = 1; p.kw = 1; p.stride = 1; p.K = L.cin; p.Kpad = L.cin; p.Cin_real = L.cin;
-    p.batch = 16; p.in_bstride = ntile * L.cin; p.w_bstride = (int64_t)L.cout * L.cin; p.out_bstride = ntile * L.cout;
+    p.batch = npos; p.in_bstride = ntile * L.cin; p.w_bstride = (int64_t)L.cout * L.cin; p.out_bstride = ntile * L.cout;
     rc = conv_forward(p, s);
     if (rc != MM_OK) return rc;
-    return wino_output_transform(M, L.bias, out, B, H, W, L.cout, L.relu, s);
+    return wino_output_transform(M, L.bias, out, B, H, W, L.cout, L.relu, m, s);
 }
 
 struct Bump {
@@ -173,7 +192,7 @@ struct mm_resnet50 {
     mm::Layer stem;
     std::vector<mm::Bottleneck> blocks;
     int ceil_mode;
-    int winograd;  // use the Winograd path for the layers that have Winograd-domain weights
+    int winograd;  // 0 direct, 2 = F(2x2,3x3), 4 = F(4x4,3x3) for the layers that have Winograd-domain weights
 };
 
 struct mm_head {
@@ -201,6 +220,7 @@ static int64_t resnet_blob_floats() {
 
 // per-frame workspace floats (see mm_resnet50_forward)
 static const int64_t kRsIn4 = 224 * 224 * 4, kRsBig = 112 * 112 * 64, kRsMid = 56 * 56 * 128;
+static const int64_t kRsWino = 36 * 14 * 14 * 64;   // largest Winograd plane set: conv2_x under F(4x4,3x3) (> kRsMid)
 
 static int64_t head_blob_floats() {
     int64_t n = 0;
@@ -257,7 +277,7 @@ int mm_resnet50_create(mm_resnet50_t** out, const float* blob, int64_t n_floats,
     h->ceil_mode = maxpool_ceil_mode;
     const float* p = blob;
     int rc = MM_OK;
-    h->winograd = 1;
+    h->winograd = 4;
     auto conv_bn = [&](Layer& L, int cout, int cin, int k, int stride, int pad, int relu) {
         const float* w = p;
         p += (int64_t)cout * cin * k * k;
@@ -299,12 +319,14 @@ int mm_resnet50_destroy(mm_resnet50_t* h) {
 int64_t mm_resnet50_workspace_bytes(mm_resnet50_t* h, int64_t batch) {
     using namespace mm;
     if (!h || batch < 0) return MM_ERR_INVALID_ARG;
-    return Bump::size_of(batch * kRsIn4) + 3 * Bump::size_of(batch * kRsBig) + 4 * Bump::size_of(batch * kRsMid);
+    return Bump::size_of(batch * kRsIn4) + 3 * Bump::size_of(batch * kRsBig) + 2 * Bump::size_of(batch * kRsMid) +
+           2 * Bump::size_of(batch * kRsWino);
 }
 
 int mm_resnet50_set_winograd(mm_resnet50_t* h, int enable) {
     if (!h) return MM_ERR_INVALID_ARG;
-    h->winograd = enable ? 1 : 0;
+    if (enable != 0 && enable != 1 && enable != 2 && enable != 4) return MM_ERR_INVALID_ARG;
+    h->winograd = enable == 1 ? 4 : enable;   // 1 = default variant
     return MM_OK;
 }
 
@@ -322,8 +344,8 @@ int mm_resnet50_forward(mm_resnet50_t* h, const float* images, int nchw, int64_t
     float* big[3] = {ws.take(batch * kRsBig), ws.take(batch * kRsBig), ws.take(batch * kRsBig)};
     float* y1 = ws.take(batch * kRsMid);
     float* y2 = ws.take(batch * kRsMid);
-    float* wv = ws.take(batch * kRsMid);   // Winograd V: 16 * tiles * C floats per frame <= 56*56*128 for conv3_x..conv5_x
-    float* wm = ws.take(batch * kRsMid);   // Winograd M
+    float* wv = ws.take(batch * kRsWino);  // Winograd V: (m+2)^2 * tiles * C floats per frame
+    float* wm = ws.take(batch * kRsWino);  // Winograd M
     int rc;
     const float* x0 = images;
     if (nchw) {
@@ -361,9 +383,10 @@ int mm_resnet50_forward(mm_resnet50_t* h, const float* images, int nchw, int64_t
         }
         rc = run_layer(Bk.reduce, x, B, H, W, C, 0, y1, Bk.reduce.cout, 0, nullptr, 0, s, &H1, &W1);
         if (rc != MM_OK) return rc;
-        if (h->winograd && Bk.conv3.wino_u &&
-            (int64_t)16 * ((H1 + 1) / 2) * ((W1 + 1) / 2) * Bk.conv3.cin <= kRsMid) {
-            rc = run_layer_wino(Bk.conv3, y1, B, H1, W1, y2, wv, wm, s);
+        const int wm_ = h->winograd;
+        if (wm_ && Bk.conv3.wino_u &&
+            (int64_t)(wm_ + 2) * (wm_ + 2) * ((H1 + wm_ - 1) / wm_) * ((W1 + wm_ - 1) / wm_) * Bk.conv3.cin <= kRsWino) {
+            rc = run_layer_wino(Bk.conv3, y1, B, H1, W1, y2, wv, wm, wm_, s);
             H2 = H1; W2 = W1;
         } else {
             rc = run_layer(Bk.conv3, y1, B, H1, W1, Bk.reduce.cout, 0, y2, Bk.conv3.cout, 0, nullptr, 0, s, &H2, &W2);
