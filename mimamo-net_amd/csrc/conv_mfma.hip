@@ -233,7 +233,7 @@ conv_mfma_kernel(const ConvParams p) {
         fb_off[j][0] = r * CLD + (((2 * lh) ^ g) << 2);
         fb_off[j][1] = r * CLD + (((2 * lh + 1) ^ g) << 2);
     }
-    asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" :: "n"(NL) : "memory");   // chunk 0 landed (chunk 1 still in flight)
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" :: "n"(NL) : "memory");   // chunk 0 landed (chunk 1 still in flight)
     float4 fa[TM][2], fb[TN][2];
     if (ABL) {
 #pragma unroll
@@ -244,8 +244,12 @@ conv_mfma_kernel(const ConvParams p) {
     // One barrier per 16-deep chunk.  Iteration kc: the direct-to-LDS loads of chunk kc+2 are issued first
     // (offsets computed one iteration earlier, no VALU in front of them), then the fragments of chunk kc are
     // read, offsets of chunk kc+3 are computed in the shadow of the 32 MFMAs, and the iteration ends with
-    // `s_waitcnt vmcnt(NL)` (chunk kc+1 landed, chunk kc+2 may still be in flight) + s_barrier.  Loads past
-    // the last chunk are harmless (range check -> zeros into a ring slot nobody reads).
+    // `s_waitcnt vmcnt(NL) lgkmcnt(0)` (chunk kc+1 landed, chunk kc+2 may still be in flight; THIS wave's fragment
+    // reads of chunk kc have completed) + s_barrier.  The lgkmcnt(0) is load-bearing: the asm's "memory" clobber does
+    // not order register-only instructions, and hipcc sinks MFMAs -- together with the lgkmcnt wait of the reads that
+    // feed them -- below the barrier; without it another wave's next DMA could overwrite a ring slot whose ds_reads
+    // were still pending (seen as rare corrupted 32x32 tiles on the short-K 64x64 configuration).  Loads past the
+    // last chunk are harmless (range check -> zeros into a ring slot nobody reads).
     int buf = 0, buf2 = 2;
     for (int kc = 0; kc < nk; ++kc) {
         if (!ABL || !(p.ablate & (1 | 128))) dma(buf2);
@@ -280,11 +284,11 @@ conv_mfma_kernel(const ConvParams p) {
                     }
         if (ABL && (p.ablate & 64)) __builtin_amdgcn_s_setprio(0);
         if (!ABL || !(p.ablate & 4))
-            asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" :: "n"(NL) : "memory");
+            asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" :: "n"(NL) : "memory");
         buf = buf == NBUF - 1 ? 0 : buf + 1;
         buf2 = buf2 == NBUF - 1 ? 0 : buf2 + 1;
     }
-    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");   // drain the over-issued loads before LDS is re-used
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");   // drain the over-issued loads before LDS is re-used
 
     // ---- fused epilogue.  MFMA C layout: col = lane & 31, row = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5), i.e. a
     // lane owns a 16-row strip of ONE channel.  Per-lane stores of that layout are 4-byte, row-strided and
@@ -419,8 +423,9 @@ int conv_forward(const ConvParams& p0, hipStream_t stream) {
         return launch_km<128, 128, 2, 2, 1, true>(p, stream);  // slice-major 3x3 shapes only
     }
     if (cfg == 0) {
-        if (p.Cout > 64 && m128 * n128 >= 512) cfg = 1;
-        else if (m128 * n64 >= 512) cfg = 2;
+        const int64_t nb = p.batch > 1 ? p.batch : 1;  // a batched launch (Winograd planes) fills the grid nb times over
+        if (p.Cout > 64 && m128 * n128 * nb >= 512) cfg = 1;
+        else if (m128 * n64 * nb >= 512) cfg = 2;
         else cfg = 3;
     }
     switch (cfg) {
