@@ -241,7 +241,7 @@ def main():
                      "traffic_note": "HBM bytes per step over all conv launches, rocprofv3 PMC (2*FETCH_SIZE + WRITE_SIZE)*1024, "
                                      "from profiles/ (not live)" if traffic else None,
                      "flops_per_step": work[0], "ms_per_step": ms[0], "launches_per_step": int(launches[0]),
-                     "note": "flops = executed on the matrix cores; with Winograd F(4x4,3x3) (or F(2x2,3x3)) on the conv3_x..conv5_x 3x3 layers "
+                     "note": "flops = executed on the matrix cores; with Winograd F(4x4,3x3) (or F(2x2,3x3)) on the stride-1 3x3 layers of conv2_x..conv5_x "
                              "that is less than the direct-form count (algorithmic_direct_flops_per_step = 8.108 GFLOP/frame)",
                      "algorithmic_direct_flops_per_step": 8.108e9 * n_frames,
                      "winograd": (0 if args.no_winograd else {1: 4}.get(args.winograd, args.winograd)),
