@@ -107,6 +107,35 @@ int mm_phase_diff_frames(mm_pyramid_t* h, const float* frames, int64_t n, const 
                          void* workspace, int64_t workspace_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------------------
+ * General complex steerable pyramid -- replaces `SCFpyr_PyTorch(height, nbands, scale_factor,
+ * device, precision).build(im_batch)` (api/steerable/SCFpyr_PyTorch.py:51-125 and
+ * _build_levels :127-208) with its FULL return list: hi-pass residual, every oriented band of every
+ * level, low-pass residual.  Arbitrary (non-mirrored) square images, even side <= 96 whose level
+ * grids stay even, height >= 2, 2 <= nbands <= 16; otherwise MM_ERR_UNSUPPORTED;
+ * `height > floor(log2(size)) - 2` returns MM_ERR_TOO_SMALL (the reference's RuntimeError, :90-91).
+ * The inference hot path does not go through here (mm_pyramid_* exploits the mirrored input).
+ * ------------------------------------------------------------------------------------- */
+typedef struct mm_scfpyr mm_scfpyr_t;
+int mm_scfpyr_create(mm_scfpyr_t** out, int size, int height, int nbands, int scale_factor);
+int mm_scfpyr_destroy(mm_scfpyr_t* h);
+/* Host-side constant builder exposed for testing (no GPU needed): the complex float64 multiplier
+ * of output `index` ([side][side][2], FFT index order of that output's grid; 1/side^2 and the
+ * (-i)^(nbands-1) band factor folded in).  out may be NULL to query side / is_complex only. */
+int mm_scfpyr_host_table(int size, int height, int nbands, int scale_factor, int index, double* out, int* side,
+                         int* is_complex);
+/* outputs in the order of the reference's list, flattened: 0 = hi-pass residual, then
+ * level-major bands (level 1 band 0 .. nbands-1, level 2 ...), last = low-pass residual */
+int mm_scfpyr_num_outputs(const mm_scfpyr_t* h);
+int mm_scfpyr_output_info(const mm_scfpyr_t* h, int index, int* side, int* is_complex);
+int64_t mm_scfpyr_workspace_bytes(const mm_scfpyr_t* h, int64_t n);
+/* images: device [n, size, size] float (precision 32) or double (precision 64) -- the reference's
+ * [N,1,H,W] batch.  outputs: HOST array of mm_scfpyr_num_outputs device pointers; output i is
+ * [n, side_i, side_i] (residuals, real) or [n, side_i, side_i, 2] (bands, re/im) in the same
+ * precision.  Internally float64 throughout. */
+int mm_scfpyr_build(const mm_scfpyr_t* h, const void* images, int precision, int64_t n, void* const* outputs,
+                    void* workspace, int64_t workspace_bytes, void* stream);
+
+/* ---------------------------------------------------------------------------------------
  * Convolutional networks (fp32 MFMA implicit-GEMM engine)
  * replaces: Resnet50_Extractor.get_vec (api/resnet50_extractor.py:74-83) and
  *           Two_Stream_RNN.forward (api/mimamo_net.py:129-143)

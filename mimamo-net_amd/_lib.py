@@ -30,6 +30,13 @@ SIGNATURES = {
     "mm_phase_extract": (_i, [_vp, _vp, _vp, _i64, _i64, _i64, _i, _i, _vp, _i, _i, _i, _vp]),
     "mm_phase_workspace_bytes": (_i64, [_vp, _i64]),
     "mm_phase_diff_frames": (_i, [_vp, _vp, _i64, _vp, _i64, _vp, _i, _i, _i, _vp, _i, _i, _i, _vp, _i64, _vp]),
+    "mm_scfpyr_create": (_i, [_c.POINTER(_vp), _i, _i, _i, _i]),
+    "mm_scfpyr_destroy": (_i, [_vp]),
+    "mm_scfpyr_host_table": (_i, [_i, _i, _i, _i, _i, _c.POINTER(_c.c_double), _c.POINTER(_i), _c.POINTER(_i)]),
+    "mm_scfpyr_num_outputs": (_i, [_vp]),
+    "mm_scfpyr_output_info": (_i, [_vp, _i, _c.POINTER(_i), _c.POINTER(_i)]),
+    "mm_scfpyr_workspace_bytes": (_i64, [_vp, _i64]),
+    "mm_scfpyr_build": (_i, [_vp, _vp, _i, _i64, _c.POINTER(_vp), _vp, _i64, _vp]),
     "mm_preproc_host_coeffs": (_i, [_i, _i, _i, _c.POINTER(_i), _c.POINTER(_i), _c.POINTER(_i), _i]),
     "mm_preproc_create": (_i, [_c.POINTER(_vp), _i, _i, _i, _i, _c.POINTER(_f)]),
     "mm_preproc_destroy": (_i, [_vp]),

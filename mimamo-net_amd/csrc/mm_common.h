@@ -50,6 +50,16 @@ struct PyramidTables {
 };
 int build_pyramid_tables(const PyramidConfig& c, PyramidTables& t);
 
+// Full pyramid (SCFpyr_PyTorch.build's whole return list) for a general square n0 x n0 image: one complex float64
+// multiplier table per output, in FFT (un-shifted) index order of that output's grid, with the ifft 1/side^2 and the
+// (-i)^(nbands-1) band factor folded in.  Order: hi-pass residual, bands level-major, low-pass residual.
+struct ScfOutput {
+    int side;
+    int is_complex;             // bands: 1; residuals (real part kept): 0
+    std::vector<double> table;  // [side][side][2]
+};
+int build_scf_full_tables(int n0, int height, int nbands, int scale_factor, std::vector<ScfOutput>& outs);
+
 }  // namespace mm
 
 struct mm_pyramid {

@@ -147,6 +147,89 @@ int host_level_mask(const PyramidConfig& c, int level, int band, std::vector<dou
     }
 }
 
+// Walks SCFpyr_PyTorch.build / _build_levels (SCFpyr_PyTorch.py:70-208) once for an n0 x n0 grid and emits the
+// multiplier every returned tensor applies to the (shifted) image spectrum.
+int build_scf_full_tables(int n0, int height, int nbands, int scale_factor, std::vector<ScfOutput>& outs) {
+    outs.clear();
+    if (n0 <= 0 || height < 2 || nbands < 2 || scale_factor < 1) return MM_ERR_INVALID_ARG;
+    Grid g = prepare_grid(n0);
+    std::vector<double> Xr, Yr;
+    rcos(Xr, Yr);
+    std::vector<double> YIr(Yr.size());
+    for (size_t k = 0; k < Yr.size(); ++k) YIr[k] = std::sqrt(1 - Yr[k] * Yr[k]);
+    const int lut = 1024, nl = 3 * lut + 3;
+    std::vector<double> Xc(nl), Yc(nl);
+    const int order = nbands - 1;
+    const double cst = std::pow(2.0, 2 * order) * factorial(order) * factorial(order) / (nbands * factorial(2 * order));
+    for (int k = 0; k < nl; ++k) {
+        Xc[k] = kPi * (double)(k - (2 * lut + 1)) / lut;
+        double alpha = std::fmod(Xc[k] + kPi, 2 * kPi);
+        if (alpha < 0) alpha += 2 * kPi;
+        alpha -= kPi;
+        Yc[k] = 2 * std::sqrt(cst) * std::pow(std::cos(Xc[k]), order) * (std::fabs(alpha) < kPi / 2 ? 1.0 : 0.0);
+    }
+    // (-i)^(nbands-1): exact values, the power cycles with period 4
+    static const double fre[4] = {1, 0, -1, 0}, fim[4] = {0, -1, 0, 1};
+    const double cr = fre[order & 3], ci = fim[order & 3];
+
+    // emit: real multiplier `mk` on the shifted n x n grid -> complex table in FFT order
+    auto emit = [&](const std::vector<double>& mk, int n, double re, double im, int is_complex) {
+        ScfOutput o;
+        o.side = n;
+        o.is_complex = is_complex;
+        o.table.assign((size_t)n * n * 2, 0.0);
+        const double norm = 1.0 / ((double)n * n);
+        for (int a = 0; a < n; ++a)
+            for (int b = 0; b < n; ++b) {
+                const int u = (a + n / 2) % n, v = (b + n / 2) % n;  // fftshift of an even-sized grid
+                const double m = mk[(size_t)u * n + v] * norm;
+                o.table[((size_t)a * n + b) * 2] = m * re;
+                o.table[((size_t)a * n + b) * 2 + 1] = m * im;
+            }
+        outs.push_back(std::move(o));
+    };
+
+    int n = n0;
+    std::vector<double> lo((size_t)n * n), tmp((size_t)n * n);
+    for (size_t k = 0; k < lo.size(); ++k) {
+        lo[k] = interp(g.log_rad[k], Xr, YIr);   // lo0mask
+        tmp[k] = interp(g.log_rad[k], Xr, Yr);   // hi0mask
+    }
+    emit(tmp, n, 1.0, 0.0, 0);
+    for (int l = 1; l <= height - 2; ++l) {
+        for (auto& x : Xr) x -= std::log2((double)scale_factor);
+        for (int band = 0; band < nbands; ++band) {
+            std::vector<double> Xs(nl);
+            for (int k = 0; k < nl; ++k) Xs[k] = Xc[k] + kPi * band / nbands;
+            tmp.resize((size_t)n * n);
+            for (size_t k = 0; k < tmp.size(); ++k)
+                tmp[k] = lo[k] * interp(g.angle[k], Xs, Yc) * interp(g.log_rad[k], Xr, Yr);
+            emit(tmp, n, cr, ci, 1);
+        }
+        int s, e;
+        crop_bounds(n, s, e);
+        const int m = e - s;
+        if (m <= 0 || (m & 1)) return MM_ERR_UNSUPPORTED;  // odd grids shift differently; not produced by supported sizes
+        Grid g2;
+        g2.n = m;
+        g2.log_rad.resize((size_t)m * m);
+        g2.angle.resize((size_t)m * m);
+        std::vector<double> lo2((size_t)m * m);
+        for (int i = 0; i < m; ++i)
+            for (int j = 0; j < m; ++j) {
+                const size_t src = (size_t)(i + s) * n + (j + s), dst = (size_t)i * m + j;
+                g2.log_rad[dst] = g.log_rad[src];
+                g2.angle[dst] = g.angle[src];
+                lo2[dst] = lo[src] * interp(g.log_rad[src], Xr, YIr);
+            }
+        g = g2;
+        lo.swap(lo2);
+        n = m;
+    }
+    emit(lo, n, 1.0, 0.0, 0);
+    return MM_OK;
+}
+
 int build_pyramid_tables(const PyramidConfig& c, PyramidTables& t) {
     const int S = c.size, N = 2 * S;  // 48, 96
     t.dct.resize((size_t)S * S);

@@ -44,7 +44,7 @@ class Resnet50_Extractor(object):
         self._ws = {}   # per-stream workspaces: the handle itself is stateless, so lanes on different streams may share it
 
     def set_winograd(self, mode=True):
-        """Algorithm of the stride-1 3x3 layers of conv3_x..conv5_x: True/1 = default (Winograd F(4x4,3x3)),
+        """Algorithm of the stride-1 3x3 layers of conv2_x..conv5_x: True/1 = default (Winograd F(4x4,3x3)),
         2 = F(2x2,3x3), 4 = F(4x4,3x3), False/0 = direct implicit GEMM."""
         mode = {True: 1, False: 0}.get(mode, mode)
         _lib.check(_lib.lib().mm_resnet50_set_winograd(self._handle, int(mode)), "mm_resnet50_set_winograd")

@@ -13,6 +13,9 @@ arguments and the reference's outputs are saved.
   G3 extract.npz    Tester.phase_diff_output on 3 windows (moving / edge-clamped / fast-moving)
   KAT kats.npz      torch_unwrap, torch_diff, gaussian_kernel, symmetric_extension_batch, blur
   G4 head.npz       Two_Stream_RNN(eval) with generated weights, bs in {1,3}, T=4
+  G8 scfpyr_full.npz  SCFpyr_PyTorch.build (the FULL list: hi-pass residual, every band, low-pass residual) on
+                    non-symmetric images: 96x96 height 4 / 2 bands (stored fp32, computed at precision=64) and
+                    32x32 height 3 with 4 and 3 bands (float64; complex factors (-i)^3 and (-i)^2)
   G7 sampler.npz    Snippet_Sampler.seq_ranges for N in {10,64,100,128,309} and the 13-frame window
                     ids decoded from constant-valued BMPs, + one textured BMP pass pinning
                     convert('L') + Lanczos 112->48 + /255
@@ -207,12 +210,40 @@ def g7_sampler(ref):
     print("G7", {k: v.shape for k, v in out.items()})
 
 
+SCF_FULL_CASES = [
+    # tag, size, height, nbands, n_images, seed, stored dtype
+    ("a", 96, 4, 2, 1, 8, np.float32),
+    ("b", 32, 3, 4, 2, 9, np.float64),
+    ("c", 32, 3, 3, 1, 10, np.float64),
+]
+
+
+def g8_scfpyr_full(ref):
+    out = {}
+    for tag, size, height, nbands, n, seed, dt in SCF_FULL_CASES:
+        x = weights.det_uniform("scf." + tag, (n, 1, size, size), 0.0, 1.0, seed)
+        pyr = ref.SCFpyr_PyTorch(height=height, nbands=nbands, scale_factor=2, device=torch.device("cpu"), precision=64)
+        coeff = pyr.build(torch.from_numpy(x).double())
+        torch.set_default_dtype(torch.float32)
+        assert len(coeff) == height and isinstance(coeff[1], list) and len(coeff[1]) == nbands
+        out["%s_hi" % tag] = coeff[0].numpy().astype(dt)
+        out["%s_lo" % tag] = coeff[-1].numpy().astype(dt)
+        for l in range(1, height - 1):
+            out["%s_l%d" % (tag, l)] = np.stack([b.numpy() for b in coeff[l]]).astype(dt)  # [nbands, N, s, s, 2]
+        print("G8", tag, {k: v.shape for k, v in out.items() if k.startswith(tag)})
+    np.savez_compressed(os.path.join(HERE, "scfpyr_full.npz"), **out)
+
+
 if __name__ == "__main__":
     ref = ref_shim.load()
+    if sys.argv[1:] == ["g8"]:
+        g8_scfpyr_full(ref)
+        sys.exit(0)
     g1_masks(ref)
     g2_pyramid(ref)
     g3_extract(ref)
     kats(ref)
     g4_head(ref)
     g7_sampler(ref)
+    g8_scfpyr_full(ref)
     os.system("ls -la %s" % HERE)

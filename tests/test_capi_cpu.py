@@ -71,3 +71,54 @@ def test_config_validation_and_no_silent_fallback(L):
         from mimamo_net_amd.phase_difference_extractor import Phase_Difference_Extractor
         with pytest.raises(RuntimeError):
             Phase_Difference_Extractor(4, 2, 2, [1, 2]).build_pyramid(torch.zeros(1, 13, 48, 48))
+
+
+SCF_FULL_CASES = [("a", 96, 4, 2, 1, 8, 1e-6), ("b", 32, 3, 4, 2, 9, 1e-14), ("c", 32, 3, 3, 1, 10, 1e-14)]
+
+
+def _scf_table(L, size, height, nbands, index):
+    side, cp = ctypes.c_int(), ctypes.c_int()
+    assert L.mm_scfpyr_host_table(size, height, nbands, 2, index, None, ctypes.byref(side), ctypes.byref(cp)) == 0
+    t = np.zeros((side.value, side.value, 2))
+    assert L.mm_scfpyr_host_table(size, height, nbands, 2, index, t.ctypes.data_as(ctypes.POINTER(ctypes.c_double)),
+                                  ctypes.byref(side), ctypes.byref(cp)) == 0
+    return t[..., 0] + 1j * t[..., 1], bool(cp.value)
+
+
+@pytest.mark.parametrize("case", SCF_FULL_CASES)
+def test_scfpyr_full_host_tables_reproduce_reference_build(L, golden, case):
+    """The per-output spectral multipliers of the general pyramid (mm_scfpyr_*), applied with numpy's FFT, give the
+    reference's SCFpyr_PyTorch.build outputs (hi residual, every band, lo residual; 2, 3 and 4 bands)."""
+    from mimamo_net_amd import weights
+    tag, size, height, nbands, n, seed, tol = case
+    g = golden("scfpyr_full")
+    x = weights.det_uniform("scf." + tag, (n, 1, size, size), 0.0, 1.0, seed)[:, 0].astype(np.float64)
+    F = np.fft.fft2(x)
+    nout = 2 + (height - 2) * nbands
+    for i in range(nout):
+        T, is_complex = _scf_table(L, size, height, nbands, i)
+        m = T.shape[0]
+        k = np.arange(m)
+        fa = np.where(k < m // 2, k, k - m) % size     # signed frequency, modulo the image side
+        o = np.fft.ifft2(F[:, fa][:, :, fa] * T) * (m * m)   # the table already carries ifft's 1/m^2
+        if i == 0 or i == nout - 1:
+            assert not is_complex
+            want, got = g[tag + ("_hi" if i == 0 else "_lo")], o.real
+        else:
+            assert is_complex
+            want, got = g["%s_l%d" % (tag, (i - 1) // nbands + 1)][(i - 1) % nbands], np.stack([o.real, o.imag], -1)
+        assert got.shape == want.shape
+        assert np.abs(got - want).max() < tol * max(1.0, np.abs(want).max()), (i, np.abs(got - want).max())
+
+
+def test_scfpyr_config_errors(L):
+    side, cp = ctypes.c_int(), ctypes.c_int()
+    q = lambda *a: L.mm_scfpyr_host_table(*a, 0, None, ctypes.byref(side), ctypes.byref(cp))
+    assert q(96, 5, 2, 2) == -2      # 5 > floor(log2 96) - 2 = 4: 'image too small' (SCFpyr_PyTorch.py:90-91)
+    assert q(96, 4, 1, 2) == -3      # nbands = 1 never terminates in the reference (quirk Q7)
+    assert q(128, 4, 2, 2) == -3     # larger than the LDS-resident transform supports
+    assert q(84, 4, 2, 2) == -3      # 84 -> 42 -> 21: an odd level grid (shifts differently; not supported)
+    assert q(40, 3, 2, 2) == 0 and side.value == 40
+    assert q(96, 4, 2, 2) == 0 and side.value == 96 and cp.value == 0
+    h = ctypes.c_void_p()
+    assert L.mm_scfpyr_create(ctypes.byref(h), 96, 4, 2, 2) == -5  # no device here: fails loudly

@@ -144,3 +144,64 @@ def test_error_behaviour(pkg, dev):
         Phase_Difference_Extractor(4, 2, 2, [1, 2]).build_pyramid(x.cpu())
     with pytest.raises(ValueError):
         Phase_Difference_Extractor(4, 2, 2, [1, 2]).extract([x])
+
+
+@pytest.mark.parametrize("case", [("a", 96, 4, 2, 1, 8), ("b", 32, 3, 4, 2, 9), ("c", 32, 3, 3, 1, 10)])
+@pytest.mark.parametrize("precision", [32, 64])
+def test_scfpyr_full_build_golden(pkg, golden, dev, case, precision):
+    """SCFpyr_PyTorch.build drop-in (full list incl. residuals) vs the real reference's float64 outputs."""
+    from mimamo_net_amd.scfpyr import SCFpyr_PyTorch
+    from mimamo_net_amd import weights
+    tag, size, height, nbands, n, seed = case
+    g = golden("scfpyr_full")
+    dt = torch.float32 if precision == 32 else torch.float64
+    x = torch.from_numpy(weights.det_uniform("scf." + tag, (n, 1, size, size), 0.0, 1.0, seed)).to(dev, dt)
+    pyr = SCFpyr_PyTorch(height=height, nbands=nbands, scale_factor=2, device=dev, precision=precision)
+    coeff = pyr.build(x)
+    assert len(coeff) == height and all(isinstance(c, list) and len(c) == nbands for c in coeff[1:-1])
+    assert torch.get_default_dtype() == torch.float32          # quirk Q10 deliberately not reproduced
+    # precision=32: float64 inside, one rounding at the end; case a's fixture itself is stored as fp32
+    tol = 2e-7 if precision == 32 or tag == "a" else 1e-13
+    def close(got, want):
+        assert got.dtype == dt and tuple(got.shape) == want.shape
+        err = np.abs(got.double().cpu().numpy() - want).max()
+        assert err <= tol * max(1.0, np.abs(want).max()), err
+    close(coeff[0], g[tag + "_hi"])
+    close(coeff[-1], g[tag + "_lo"])
+    for l in range(1, height - 1):
+        for b in range(nbands):
+            close(coeff[l][b], g["%s_l%d" % (tag, l)][b])
+
+
+def test_scfpyr_matches_hot_path_pyramid_on_mirrored_input(pde, pkg, oracle, dev):
+    """The general build on the mirrored 96x96 image, cropped to the kept quadrant, equals the hot-path kernel."""
+    from mimamo_net_amd.scfpyr import SCFpyr_PyTorch
+    from mimamo_net_amd import synthetic
+    frames = synthetic.textured_gray(5, 48, seed=77)
+    sym = np.stack([oracle.symmetric_extension(f) for f in frames])
+    pyr = SCFpyr_PyTorch(height=4, nbands=2, scale_factor=2, device=dev, precision=32)
+    coeff = pyr.build(torch.from_numpy(sym)[:, None].to(dev))
+    c1, c2 = pde.build_pyramid(torch.from_numpy(frames)[None].to(dev))      # [1,2,5,48,48,2], [1,2,5,24,24,2]
+    for b in range(2):
+        assert (coeff[1][b][:, :48, :48] - c1[0, b]).abs().max() < 1e-6
+        assert (coeff[2][b][:, :24, :24] - c2[0, b]).abs().max() < 1e-6
+
+
+def test_scfpyr_errors(pkg, dev):
+    from mimamo_net_amd.scfpyr import SCFpyr_PyTorch
+    pyr = SCFpyr_PyTorch(height=4, nbands=2, device=dev)
+    with pytest.raises(AssertionError):
+        pyr.build(torch.zeros(2, 1, 96, 96, device=dev, dtype=torch.float64))      # dtype (SCFpyr_PyTorch.py:82)
+    with pytest.raises(AssertionError):
+        pyr.build(torch.zeros(2, 96, 96, device=dev))                               # ndim (:83)
+    with pytest.raises(AssertionError):
+        pyr.build(torch.zeros(2, 3, 96, 96, device=dev))                            # channels (:84)
+    with pytest.raises(AssertionError):
+        pyr.build(torch.zeros(2, 1, 96, 96))                                        # device (:81)
+    with pytest.raises(RuntimeError, match="image too small"):
+        SCFpyr_PyTorch(height=5, nbands=2, device=dev).build(torch.zeros(1, 1, 48, 48, device=dev))   # :90-91
+    with pytest.raises(NotImplementedError):
+        SCFpyr_PyTorch(height=4, nbands=2, device=dev).build(torch.zeros(1, 1, 128, 128, device=dev))
+    assert [tuple(t.shape) if not isinstance(t, list) else [tuple(u.shape) for u in t]
+            for t in pyr.build(torch.zeros(0, 1, 96, 96, device=dev))] == \
+        [(0, 96, 96), [(0, 96, 96, 2)] * 2, [(0, 48, 48, 2)] * 2, (0, 24, 24)]
