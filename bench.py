@@ -143,6 +143,11 @@ def main():
 
     lengths = [FRAMES_PER_CLIP] * args.clips
 
+    # N>1: the [frames,2] results of a step are all-gathered (8 B/frame, the only collective on the path).  It is issued
+    # asynchronously on RCCL's stream and only waited for one step later, so a rank never stalls on a slower peer
+    # inside a step -- ranks are independent shards and the job time is the slowest rank's, not a sum of per-step maxima.
+    pending = []
+
     def step():
         if args.lanes > 1:
             ins = (frames_u8,) if frames_u8 is not None else (gray, rgb)
@@ -153,13 +158,17 @@ def main():
             out = hot.forward(gray, rgb, plan, independent_clips=True)  # [frames, 2]
         if world > 1:
             import torch.distributed as dist
+            while pending:
+                pending.pop()[0].wait()
             gathered = [torch.empty_like(out) for _ in range(world)]
-            dist.all_gather(gathered, out)
+            pending.append((dist.all_gather(gathered, out, async_op=True), gathered, out))
         return out
 
     def fence():
         if world > 1:
             import torch.distributed as dist
+            while pending:
+                pending.pop()[0].wait()
             dist.barrier()
         torch.cuda.synchronize()
 
