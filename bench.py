@@ -253,6 +253,9 @@ def main():
                      "note": "flops = executed on the matrix cores; with Winograd F(4x4,3x3) (or F(2x2,3x3)) on the stride-1 3x3 layers of conv2_x..conv5_x "
                              "that is less than the direct-form count (algorithmic_direct_flops_per_step = 8.108 GFLOP/frame)",
                      "algorithmic_direct_flops_per_step": 8.108e9 * n_frames,
+                     # SURVEY 8(d) figure (direct-form 8.108 GFLOP/frame) over the conv launches AND the Winograd transforms
+                     "algorithmic_equiv_tflops": 8.108e9 * n_frames / ((ms[0] + ms[3]) * 1e-3) / 1e12,
+                     "algorithmic_equiv_frac": 8.108e9 * n_frames / ((ms[0] + ms[3]) * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS,
                      "winograd": (0 if args.no_winograd else {1: 4}.get(args.winograd, args.winograd)),
                      "winograd_transforms": {"ms_per_step": ms[3], "bytes_per_step": work[3], "launches_per_step": int(launches[3]),
                                              "GB_per_s": (work[3] / (ms[3] * 1e-3) / 1e9) if ms[3] > 0 else None}},

@@ -310,26 +310,29 @@ conv_mfma_kernel(const ConvParams p) {
             ps4 = *reinterpret_cast<const float4*>(p.post_scale + n0);
             pt4 = *reinterpret_cast<const float4*>(p.post_shift + n0);
         }
+        // Every wave stages through its OWN 32 x WN region, so no workgroup barrier is needed in here: LDS operations
+        // of one wave execute in issue order (its ds_reads see its earlier ds_writes, whichever lane wrote them).  The
+        // residual rows of a pass are requested before the pass is staged so their HBM latency overlaps the transpose.
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
+            const int m0 = m_base + wm * WM + i * 32;
+            float4 v[32 / RPI], rsd[32 / RPI];
+            if (p.res) {
+#pragma unroll
+                for (int t = 0; t < 32 / RPI; ++t) {
+                    const int m = m0 + t * RPI + qr;
+                    const int64_t mo = (nok && m < p.M) ? (int64_t)m * p.res_cstride + p.res_coff + n0 : 0;
+                    rsd[t] = *reinterpret_cast<const float4*>(p.res + mo);
+                }
+            }
 #pragma unroll
             for (int j = 0; j < TN; ++j)
 #pragma unroll
                 for (int e = 0; e < 16; ++e)
                     st[((e & 3) + 8 * (e >> 2) + 4 * lh) * SLD + j * 32 + lr] = acc[i][j][e];
-            __syncthreads();
-            const int m0 = m_base + wm * WM + i * 32;
-            float4 v[32 / RPI], rsd[32 / RPI];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
 #pragma unroll
-            for (int t = 0; t < 32 / RPI; ++t) {
-                const int row = t * RPI + qr;
-                v[t] = *reinterpret_cast<const float4*>(st + row * SLD + qc * 4);
-                const int m = m0 + row;
-                if (p.res) {
-                    const int64_t mo = (nok && m < p.M) ? (int64_t)m * p.res_cstride + p.res_coff + n0 : 0;
-                    rsd[t] = *reinterpret_cast<const float4*>(p.res + mo);
-                }
-            }
+            for (int t = 0; t < 32 / RPI; ++t) v[t] = *reinterpret_cast<const float4*>(st + (t * RPI + qr) * SLD + qc * 4);
 #pragma unroll
             for (int t = 0; t < 32 / RPI; ++t) {
                 const int m = m0 + t * RPI + qr;
@@ -342,7 +345,7 @@ conv_mfma_kernel(const ConvParams p) {
                 }
                 if (nok && m < p.M) *reinterpret_cast<float4*>(out_b + (int64_t)m * p.out_cstride + p.out_coff + n0) = o;
             }
-            if (i + 1 < TM) __syncthreads();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");   // pass i+1 re-writes the region these reads came from
         }
         return;
     }
