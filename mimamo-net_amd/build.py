@@ -12,7 +12,7 @@ LIB = os.path.join(HERE, "libmimamo_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 ARCH = "gfx950"
 FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
-         "-I" + os.path.join(os.path.dirname(HERE), "include")]
+         "-I" + os.path.join(os.path.dirname(HERE), "include")] + os.environ.get("MM_EXTRA_HIPCC_FLAGS", "").split()
 
 
 def _sources():
