@@ -94,6 +94,25 @@ def test_lanes_on_several_streams_are_bit_identical(tester):
             assert torch.equal(a, b)
 
 
+def test_bench_sized_step_is_deterministic(tester):
+    """BASELINE configs[3] at bench size (32 clips x 64 frames, two lanes): chip-filling launches of every kernel on the
+    path are bit-identical run to run and equal to the single-stream pass (load-dependent races show up here first)."""
+    dev = tester.device
+    g = torch.Generator(device="cpu").manual_seed(5)
+    n = 32 * 64
+    gray = torch.rand(n, 48, 48, generator=g).to(dev)
+    rgb = (torch.rand(n, 224, 224, 4, generator=g) * 200 - 100).to(dev)
+    rgb[..., 3] = 0
+    lengths = [64] * 32
+    with torch.no_grad():
+        a = tester.hot.forward_lanes((gray, rgb), lengths, 2, independent_clips=True)
+        b = tester.hot.forward_lanes((gray, rgb), lengths, 2, independent_clips=True)
+        c = tester.hot.forward(gray, rgb, tester.hot.plan(lengths), independent_clips=True)
+        torch.cuda.synchronize()
+    assert torch.isfinite(a).all()
+    assert torch.equal(a, b) and torch.equal(a, c)
+
+
 def test_reference_style_dataloader_loop_matches_fused_path(tester, oracle):
     """Tester.test_on_dataloader (windowed input, api/tester.py:76-121) == the fused de-duplicated pipeline."""
     n = 100
