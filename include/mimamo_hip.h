@@ -16,7 +16,9 @@
  *     per-device constant tables (masks, DFT twiddles, BN-folded weights).
  *   - calls only ENQUEUE work on `stream`; no hidden synchronisation (the reference's
  *     device->host assert at api/phase_difference_extractor.py:105 is deliberately dropped).
- *   - one handle per (process, device); calls on different handles are re-entrant.
+ *   - one handle per (process, device); calls on different handles are re-entrant.  A handle is bound to
+ *     the device that was current at mm_*_create: enqueueing with another current device returns
+ *     MM_ERR_INVALID_ARG instead of handing one GPU's pointers to another.
  *   - all arithmetic is fp32 (the reference pins torch.float32, SCFpyr_PyTorch.py:57-59).
  */
 #ifndef MIMAMO_HIP_H

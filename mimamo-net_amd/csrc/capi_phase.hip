@@ -97,6 +97,7 @@ int mm_pyramid_destroy(mm_pyramid_t* h) {
 int mm_pyramid_build(mm_pyramid_t* h, const float* frames, int64_t n, float* c1, int64_t is1, int64_t bs1, float* c2,
                      int64_t is2, int64_t bs2, void* stream) {
     if (!h || n < 0 || (n > 0 && (!frames || !c1 || !c2))) return MM_ERR_INVALID_ARG;
+    MM_CHECK_DEVICE(h);
     return mm::launch_pyramid(h, frames, n, n, c1, 0, is1, bs1, c2, 0, is2, bs2, 0, (hipStream_t)stream);
 }
 
@@ -105,6 +106,7 @@ int mm_pyramid_build(mm_pyramid_t* h, const float* frames, int64_t n, float* c1,
 int mm_pyramid_build_batch(mm_pyramid_t* h, const float* im_batch, int64_t B, int64_t P, float* c1, float* c2,
                            void* stream) {
     if (!h || B < 0 || P <= 0 || (B > 0 && (!im_batch || !c1 || !c2))) return MM_ERR_INVALID_ARG;
+    MM_CHECK_DEVICE(h);
     const int64_t S = h->cfg.size, nb = h->cfg.nbands;
     const int64_t plane1 = S * S * 2, plane2 = (S / 2) * (S / 2) * 2;
     return mm::launch_pyramid(h, im_batch, B * P, P, c1, nb * P * plane1, plane1, P * plane1, c2, nb * P * plane2,
@@ -114,6 +116,7 @@ int mm_pyramid_build_batch(mm_pyramid_t* h, const float* im_batch, int64_t B, in
 int mm_phase_extract(mm_pyramid_t* h, const float* coeff, const int32_t* ids, int64_t img_stride, int64_t band_stride,
                      int64_t J, int P, int W, float* out, int out_nhwc, int out_cstride, int out_coffset, void* stream) {
     if (!h || J < 0 || (J > 0 && (!coeff || !ids || !out))) return MM_ERR_INVALID_ARG;
+    MM_CHECK_DEVICE(h);
     if (P != 13) return MM_ERR_UNSUPPORTED;  // num_phase = 12 (api/tester.py:28)
     if (W != h->cfg.size && W != h->cfg.size / 2) return MM_ERR_UNSUPPORTED;
     if (out_nhwc && (out_cstride < out_coffset + 2 * (P - 1) || out_coffset < 0 || (out_cstride | out_coffset) & 3))
@@ -133,6 +136,7 @@ int mm_phase_diff_frames(mm_pyramid_t* h, const float* frames, int64_t n, const 
                          int out1_cstride, int out1_coffset, void* workspace, int64_t workspace_bytes, void* stream) {
     if (!h || n <= 0 || J < 0 || !frames || !ids || !out0 || !out1 || !workspace) return MM_ERR_INVALID_ARG;
     if (workspace_bytes < mm_phase_workspace_bytes(h, n)) return MM_ERR_WORKSPACE;
+    MM_CHECK_DEVICE(h);
     const int64_t S = h->cfg.size, nb = h->cfg.nbands;
     const int64_t plane1 = S * S * 2, plane2 = (S / 2) * (S / 2) * 2;
     float* c1 = (float*)workspace;           // [n][nb][S][S][2]

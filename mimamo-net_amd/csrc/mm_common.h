@@ -26,6 +26,17 @@ inline int hip_fail(hipError_t e) {
         if (_e != hipSuccess) return mm::hip_fail(_e); \
     } while (0)
 
+// A handle's tables / weights live on the device that was current at mm_*_create; using it with another current
+// device would hand the kernels pointers of a different GPU.
+inline int current_device_or(int fallback) {
+    int d = fallback;
+    return hipGetDevice(&d) == hipSuccess ? d : fallback;
+}
+#define MM_CHECK_DEVICE(h)                                                   \
+    do {                                                                     \
+        if (mm::current_device_or(-1) != (h)->device) return MM_ERR_INVALID_ARG; \
+    } while (0)
+
 // ---- optional launch timing (profile.hip)
 bool prof_enabled();
 void prof_before(int cat, double work, hipStream_t s, const char* tag = nullptr);

@@ -193,12 +193,14 @@ struct mm_resnet50 {
     std::vector<mm::Bottleneck> blocks;
     int ceil_mode;
     int winograd;  // 0 direct, 2 = F(2x2,3x3), 4 = F(4x4,3x3) for the layers that have Winograd-domain weights
+    int device;
 };
 
 struct mm_head {
     mm::DeviceArena arena;
     mm::Layer mlp1, mlp2, conv[6], fc1, fc2, transform, gru_ih[2], gru_hh[2][2], classifier;
     float* bhh[2][2];
+    int device;
 };
 
 namespace mm {
@@ -275,6 +277,7 @@ int mm_resnet50_create(mm_resnet50_t** out, const float* blob, int64_t n_floats,
     mm_resnet50* h = new (std::nothrow) mm_resnet50();
     if (!h) return MM_ERR_INVALID_ARG;
     h->ceil_mode = maxpool_ceil_mode;
+    h->device = current_device_or(0);
     const float* p = blob;
     int rc = MM_OK;
     h->winograd = 4;
@@ -336,6 +339,7 @@ int mm_resnet50_forward(mm_resnet50_t* h, const float* images, int nchw, int64_t
     if (!h || batch < 0 || (batch > 0 && (!images || !out || !workspace))) return MM_ERR_INVALID_ARG;
     if (batch == 0) return MM_OK;
     if (batch > 40000) return MM_ERR_INVALID_ARG;  // M = batch*112*112 must fit int32
+    MM_CHECK_DEVICE(h);
     if (workspace_bytes < mm_resnet50_workspace_bytes(h, batch)) return MM_ERR_WORKSPACE;
     hipStream_t s = (hipStream_t)stream_;
     const int B = (int)batch;
@@ -414,6 +418,7 @@ int mm_head_create(mm_head_t** out, const float* blob, int64_t n_floats) {
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return MM_ERR_NO_DEVICE;
     mm_head* h = new (std::nothrow) mm_head();
     if (!h) return MM_ERR_INVALID_ARG;
+    h->device = current_device_or(0);
     const float eps = 1e-5f;
     const float* p = blob;
     int rc = MM_OK;
@@ -511,6 +516,7 @@ int mm_head_forward(mm_head_t* h, const float* phase_0, const float* phase_1, in
     if (N64 == 0) return MM_OK;
     if (!phase_0 || !phase_1 || !rgb || !out || !workspace || N64 > 400000) return MM_ERR_INVALID_ARG;
     if (workspace_bytes < mm_head_workspace_bytes(h, bs, T)) return MM_ERR_WORKSPACE;
+    MM_CHECK_DEVICE(h);
     hipStream_t s = (hipStream_t)stream_;
     const int N = (int)N64;
     const HeadWs z = head_sizes(N64, T);

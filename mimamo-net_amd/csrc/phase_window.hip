@@ -24,7 +24,12 @@ constexpr int TAP = 11, R = 5; // gaussian_kernel(std=2, tap=11), phase_utils.py
 constexpr int PX = 4;          // pixels per thread (one float4)
 constexpr int PADX = 8;        // the row pass reads [x0-8, x0+12): two float4 slots of halo on each side
 
-__constant__ float c_gauss[TAP];  // exp(-d^2/8), d=-5..5 ; the 2-D kernel is its outer product
+// (float)exp(-d^2/8), d = -5..5 (exact decimal expansions of the fp32 values); the 2-D kernel is its outer product.
+// Compile-time constants: no per-device symbol upload, the taps fold into the FMAs as literals.
+__device__ constexpr float c_gauss[TAP] = {0.043936934322118759f, 0.1353352814912796f, 0.32465246319770813f,
+                                           0.60653066635131836f,  0.88249689340591431f, 1.0f,
+                                           0.88249689340591431f,  0.60653066635131836f, 0.32465246319770813f,
+                                           0.1353352814912796f,   0.043936934322118759f};
 
 template <int W>
 struct WinCfg {
@@ -223,22 +228,9 @@ phase_window_kernel(const float* __restrict__ coeff, const int32_t* __restrict__
     }
 }
 
-static int upload_gauss() {
-    float g[TAP];
-    for (int t = 0; t < TAP; ++t) g[t] = (float)exp(-(double)((t - R) * (t - R)) / 8.0);
-    MM_HIP(hipMemcpyToSymbol(HIP_SYMBOL(c_gauss), g, sizeof(g)));
-    return MM_OK;
-}
-
 int launch_phase_window(const float* coeff, const int32_t* ids, int64_t img_stride, int64_t band_stride, int64_t J,
                         int W, float* out, int out_nhwc, int out_cstride, int out_coffset, int polar, hipStream_t stream) {
     if (J <= 0) return MM_OK;
-    static bool gauss_ready = false;
-    if (!gauss_ready) {
-        int rc = upload_gauss();
-        if (rc != MM_OK) return rc;
-        gauss_ready = true;
-    }
     const dim3 grid((unsigned)(2 * J));
     prof_before(2, (double)J * 2 * (P - 1) * W * W * 4, stream);  // algorithmic write: 24 phase-difference planes
 #define MM_WIN(WW, PP)                                                                                                  \

@@ -187,6 +187,7 @@ struct mm_preproc {
     float mean[3];
     mm::ResampleTable lan, bil;
     int *d_lan_bounds = nullptr, *d_lan_kk = nullptr, *d_bil_bounds = nullptr, *d_bil_kk = nullptr;
+    int device = 0;
 };
 
 extern "C" {
@@ -215,6 +216,7 @@ int mm_preproc_create(mm_preproc_t** out, int in_size, int gray_size, int resize
     mm_preproc* h = new (std::nothrow) mm_preproc();
     if (!h) return MM_ERR_INVALID_ARG;
     h->in_size = in_size; h->gray_size = gray_size; h->resize = resize; h->crop = crop;
+    h->device = mm::current_device_or(0);
     for (int c = 0; c < 3; ++c) h->mean[c] = mean3[c];
     int rc = mm::build_resample_table(in_size, gray_size, 1, h->lan);
     if (rc == MM_OK) rc = mm::build_resample_table(in_size, resize, 0, h->bil);
@@ -247,6 +249,7 @@ int mm_preproc_forward(mm_preproc_t* h, const uint8_t* frames, int64_t n, float*
                        void* stream_) {
     if (!h || n < 0 || (n > 0 && !frames) || (!gray_out && !rgb_out)) return MM_ERR_INVALID_ARG;
     if (n == 0) return MM_OK;
+    MM_CHECK_DEVICE(h);
     hipStream_t s = (hipStream_t)stream_;
     if (gray_out) {
         const int lds = h->in_size * h->in_size + h->in_size * h->gray_size;

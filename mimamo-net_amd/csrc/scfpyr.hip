@@ -244,6 +244,7 @@ int mm_scfpyr_build(const mm_scfpyr_t* h, const void* images, int precision, int
     if (workspace_bytes < mm_scfpyr_workspace_bytes(h, n)) return MM_ERR_WORKSPACE;
     for (int i = 0; i < h->n_out; ++i)
         if (!outputs[i]) return MM_ERR_INVALID_ARG;
+    MM_CHECK_DEVICE(h);
     hipStream_t s = (hipStream_t)stream;
     double2* F = (double2*)workspace;
     const int n0 = h->size;
