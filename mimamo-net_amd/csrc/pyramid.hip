@@ -293,12 +293,9 @@ int launch_pyramid(const mm_pyramid* h, const float* frames, int64_t n, int64_t 
     if (n <= 0) return MM_OK;
     static_assert(L_TOTAL * 4 <= 160 * 1024, "LDS budget");
     const int lds_bytes = L_TOTAL * 4;
-    static bool attr_set = false;
-    if (!attr_set) {
-        MM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(pyramid_kernel),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
-        attr_set = true;
-    }
+    // per launch (microseconds): the attribute belongs to the current device's copy of the kernel
+    MM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(pyramid_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               lds_bytes));
     int64_t grid = 2 * n;
     if (grid > 1024) grid = 1024;  // 256 CUs x 1 resident workgroup; the rest grid-strides
     prof_before(1, (double)n * (S * S * 4), stream);  // algorithmic read of the stage: one fp32 frame
