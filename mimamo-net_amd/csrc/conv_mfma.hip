@@ -343,7 +343,11 @@ conv_mfma_kernel(const ConvParams p) {
                 if (p.post_scale) {
                     o.x = o.x * ps4.x + pt4.x; o.y = o.y * ps4.y + pt4.y; o.z = o.z * ps4.z + pt4.z; o.w = o.w * ps4.w + pt4.w;
                 }
-                if (nok && m < p.M) *reinterpret_cast<float4*>(out_b + (int64_t)m * p.out_cstride + p.out_coff + n0) = o;
+                if (nok && m < p.M) {
+                    typedef float f32x4_t __attribute__((ext_vector_type(4)));
+                    const f32x4_t ov = {o.x, o.y, o.z, o.w};
+                    __builtin_nontemporal_store(ov, reinterpret_cast<f32x4_t*>(out_b + (int64_t)m * p.out_cstride + p.out_coff + n0));
+                }
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");   // pass i+1 re-writes the region these reads came from
         }

@@ -10,6 +10,19 @@
 
 namespace mm {
 
+// streaming (non-temporal) 16-byte store: planes and activations are consumed by a later kernel from HBM, not from L2
+__device__ __forceinline__ float4 nt_load(const float4* p) {
+    typedef float f32x4_t __attribute__((ext_vector_type(4)));
+    const f32x4_t x = __builtin_nontemporal_load(reinterpret_cast<const f32x4_t*>(p));
+    return float4{x.x, x.y, x.z, x.w};
+}
+__device__ __forceinline__ void nt_store(float4* p, const float4& v) {
+    typedef float f32x4_t __attribute__((ext_vector_type(4)));
+    const f32x4_t x = {v.x, v.y, v.z, v.w};
+    __builtin_nontemporal_store(x, reinterpret_cast<f32x4_t*>(p));
+}
+
+
 // one thread: one tile, four consecutive channels
 __global__ void __launch_bounds__(256)
 wino_in_kernel(const float* __restrict__ x, float* __restrict__ V, int B, int H, int W, int C4, int TH, int TW, int64_t total) {
@@ -166,7 +179,7 @@ wino_in6_kernel(const float* __restrict__ x, float* __restrict__ V, int B, int H
         float4 v[6];
         bt6(col, v);
 #pragma unroll
-        for (int r = 0; r < 6; ++r) dst[((int64_t)(r * 6 + q) * ntile + tile) * C4 + c4] = v[r];
+        for (int r = 0; r < 6; ++r) nt_store(&dst[((int64_t)(r * 6 + q) * ntile + tile) * C4 + c4], v[r]);
     }
 }
 
@@ -187,7 +200,7 @@ wino_out6_kernel(const float* __restrict__ M, const float* __restrict__ bias, fl
     for (int q = 0; q < 6; ++q) {   // A^T along the rows of every column
         float4 col[6];
 #pragma unroll
-        for (int r = 0; r < 6; ++r) col[r] = src[((int64_t)(r * 6 + q) * ntile + tile) * C4 + c4];
+        for (int r = 0; r < 6; ++r) col[r] = nt_load(&src[((int64_t)(r * 6 + q) * ntile + tile) * C4 + c4]);  // read exactly once
         float4 o[4];
         at6(col, o);
 #pragma unroll
@@ -206,7 +219,7 @@ wino_out6_kernel(const float* __restrict__ M, const float* __restrict__ bias, fl
             if (hy < H && wx < W) {
                 float4 v = f4add(o[q], bs);
                 if (relu) v = float4{fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f)};
-                dst[((b * H + hy) * W + wx) * C4 + c4] = v;
+                nt_store(&dst[((b * H + hy) * W + wx) * C4 + c4], v);
             }
         }
     }
