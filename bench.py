@@ -103,7 +103,7 @@ def main():
     ap.add_argument("--same-device", action="store_true", help="testing only: every rank uses cuda:0")
     ap.add_argument("--no-winograd", action="store_true", help="run every 3x3 layer in the direct implicit-GEMM form")
     ap.add_argument("--winograd", type=int, default=1, help="1 = default variant (F(4x4,3x3)), 2 = F(2x2,3x3), 4 = F(4x4,3x3)")
-    ap.add_argument("--lanes", type=int, default=2, help="HIP streams the clips of a step are spread over (1 = single stream)")
+    ap.add_argument("--lanes", type=int, default=3, help="HIP streams the clips of a step are spread over (1 = single stream)")
     ap.add_argument("--from-u8", action="store_true",
                     help="start every step from the raw boundary (uint8 112x112x3 aligned faces in HBM): adds the "
                          "PIL-exact on-GPU preprocessing to the timed region")
