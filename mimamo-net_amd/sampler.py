@@ -60,6 +60,19 @@ def list_aligned_frames(opface_dir, video_name):
     return out
 
 
+def load_u8_batch(paths, size=112):
+    """Decoded RGB frames as one uint8 array [n,size,size,3], or None when a frame has another size (then the
+    host-side PIL preprocessing below applies)."""
+    from PIL import Image
+    out = np.empty((len(paths), size, size, 3), dtype=np.uint8)
+    for i, p in enumerate(paths):
+        im = Image.open(p).convert('RGB')
+        if im.size != (size, size):
+            return None
+        out[i] = np.asarray(im, dtype=np.uint8)
+    return out
+
+
 def load_rgb_batch(paths, mean=RESNET50_MEAN):
     """BMP -> Resize(256, bilinear) -> CenterCrop(224) -> ToTensor -> x255 -> -mean (utils/model_utils.py:29-39).
     Returns a CPU float tensor [n,3,224,224]."""

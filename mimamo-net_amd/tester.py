@@ -26,7 +26,7 @@ class Tester(object):
                  head_state_dict=None, resnet_state_dict=None, device=None):
         if (num_phase, phase_size, height, nbands, scale_factor, list(extract_level)) != (12, 48, 4, 2, 2, [1, 2]):
             raise NotImplementedError("only the published configuration (api/tester.py:28-32) is implemented")
-        self.batch_size, self.workers = batch_size, workers
+        self.batch_size, self.workers, self.save_size = batch_size, workers, save_size
         self.num_phase, self.phase_size, self.length, self.stride = num_phase, phase_size, length, stride
         self.label_name = ['valence', 'arousal']  # api/tester.py:52
         if head_state_dict is None:
@@ -97,7 +97,12 @@ class Tester(object):
                                "(api/video_processor.py:69-84); the face tracker is outside this build" % opface_output_dir)
         frames = sampler.list_aligned_frames(opface_output_dir, video_name)
         paths = [p for _, p in frames]
-        gray = sampler.load_gray_batch(paths, self.phase_size).to(self.device)
+        u8 = sampler.load_u8_batch(paths, self.save_size)
+        if u8 is not None:
+            # OpenFace's -simsize 112 crops (api/video_processor.py:75): decode only on the host, resize / crop /
+            # normalise on the GPU -- bit-exact with the PIL calls of the reference's samplers (csrc/preproc.hip)
+            return self.test_frames([u8], names=[video_name])
+        gray = sampler.load_gray_batch(paths, self.phase_size).to(self.device)   # other frame sizes: PIL on the host
         rgb = sampler.load_rgb_batch(paths).to(self.device)
         res = self._run([len(paths)], gray, rgb)
         return {video_name: pd.DataFrame(data=res[0], columns=self.label_name)}
