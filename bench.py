@@ -101,6 +101,9 @@ def main():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL; gloo only for "
                     "plumbing tests of the multi-process path on a single GPU, together with --same-device)")
     ap.add_argument("--same-device", action="store_true", help="testing only: every rank uses cuda:0")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="testing only: run the N>1 code path (process group, async all-gather, barrier) even with one rank, "
+                         "to exercise it over RCCL on a single-GPU box")
     ap.add_argument("--no-winograd", action="store_true", help="run every 3x3 layer in the direct implicit-GEMM form")
     ap.add_argument("--winograd", type=int, default=1, help="1 = default variant (F(4x4,3x3)), 2 = F(2x2,3x3), 4 = F(4x4,3x3)")
     ap.add_argument("--lanes", type=int, default=3, help="HIP streams the clips of a step are spread over (1 = single stream)")
@@ -113,12 +116,15 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.cuda.set_device(0 if args.same_device else local_rank)
-        dist.init_process_group(backend=args.backend, rank=rank, world_size=world)
+        kw = {"device_id": torch.device("cuda", torch.cuda.current_device())} if args.backend == "nccl" else {}
+        dist.init_process_group(backend=args.backend, rank=rank, world_size=world, **kw)
     else:
         torch.cuda.set_device(0)
     device = torch.device("cuda", torch.cuda.current_device())
@@ -156,7 +162,7 @@ def main():
             out = hot.forward_u8(frames_u8, plan, independent_clips=True)
         else:
             out = hot.forward(gray, rgb, plan, independent_clips=True)  # [frames, 2]
-        if world > 1:
+        if use_dist:
             import torch.distributed as dist
             while pending:
                 pending.pop()[0].wait()
@@ -165,7 +171,7 @@ def main():
         return out
 
     def fence():
-        if world > 1:
+        if use_dist:
             import torch.distributed as dist
             while pending:
                 pending.pop()[0].wait()
@@ -181,7 +187,7 @@ def main():
             out = step()
         fence()
         dt = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         import torch.distributed as dist
         t = torch.tensor([dt], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -275,7 +281,7 @@ def main():
         else:
             result["cpu_baseline"] = None
         print(json.dumps(result))
-    if world > 1:
+    if use_dist:
         import torch.distributed as dist
         dist.destroy_process_group()
 
