@@ -118,6 +118,31 @@ def test_bench_sized_step_is_deterministic(tester):
     assert torch.equal(a, b) and torch.equal(a, c)
 
 
+def test_hot_path_is_hip_graph_capturable(tester):
+    """The C ABI only enqueues on the given stream (no hidden synchronisation, allocation or host copy): one pass of the
+    whole path can be captured in a HIP graph and replayed on new input values with bit-identical results."""
+    dev = tester.device
+    g = torch.Generator(device="cpu").manual_seed(9)
+    gray = torch.rand(64, 48, 48, generator=g).to(dev)
+    rgb = (torch.rand(64, 224, 224, 4, generator=g) * 200 - 100).to(dev)
+    plan = tester.hot.plan([64])
+    with torch.no_grad():
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            tester.hot.forward(gray, rgb, plan, independent_clips=True)     # warm-up outside capture (workspaces)
+        torch.cuda.current_stream().wait_stream(s)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            out = tester.hot.forward(gray, rgb, plan, independent_clips=True)
+        gray2, rgb2 = gray.flip(0).contiguous(), rgb.flip(0).contiguous()
+        want = tester.hot.forward(gray2, rgb2, plan, independent_clips=True).clone()
+        gray.copy_(gray2); rgb.copy_(rgb2)          # new values in the captured input buffers
+        graph.replay()
+        torch.cuda.synchronize()
+    assert torch.equal(out, want)
+
+
 def test_reference_style_dataloader_loop_matches_fused_path(tester, oracle):
     """Tester.test_on_dataloader (windowed input, api/tester.py:76-121) == the fused de-duplicated pipeline."""
     n = 100
