@@ -133,6 +133,23 @@ def test_full_size_properties(pde, dev):
     assert s0.abs().max() == 0 and s1.abs().max() == 0
 
 
+def test_degenerate_frames_stay_finite_and_match_oracle(pde, oracle, dev):
+    """Spatially constant / all-zero frames have (numerically) zero band coefficients: magnitude = the reference's 1e-10
+    EPS term, phase = atan2 of rounding noise.  Nothing may become NaN/Inf, and an all-zero clip gives exact zeros in
+    the oracle and on the GPU alike (atan2(0,0) = 0, 0*0/1e-10... = 0)."""
+    n = 16
+    ids = oracle.window_ids(0, n, n).astype(np.int32)
+    zeros = np.zeros((n, 48, 48), dtype=np.float32)
+    z0, z1 = pde.phase_diff_frames(torch.from_numpy(zeros).to(dev), torch.from_numpy(ids).to(dev))
+    o0, o1 = oracle.phase_diff_from_frames(zeros, ids)
+    assert np.isfinite(o0).all() and np.abs(o0).max() == 0 and np.abs(o1).max() == 0
+    assert z0.abs().max() == 0 and z1.abs().max() == 0
+    const = np.full((n, 48, 48), 0.37, dtype=np.float32) * np.linspace(0.5, 1.0, n, dtype=np.float32)[:, None, None]
+    c0, c1 = pde.phase_diff_frames(torch.from_numpy(const).to(dev), torch.from_numpy(ids).to(dev))
+    assert torch.isfinite(c0).all() and torch.isfinite(c1).all()
+    assert c0.abs().max() <= 5 * np.pi + 1e-5 and c1.abs().max() <= 5 * np.pi + 1e-5
+
+
 def test_error_behaviour(pkg, dev):
     from mimamo_net_amd.phase_difference_extractor import Phase_Difference_Extractor
     x = torch.zeros(1, 13, 48, 48, device=dev)
