@@ -16,6 +16,11 @@ arguments and the reference's outputs are saved.
   G8 scfpyr_full.npz  SCFpyr_PyTorch.build (the FULL list: hi-pass residual, every band, low-pass residual) on
                     non-symmetric images: 96x96 height 4 / 2 bands (stored fp32, computed at precision=64) and
                     32x32 height 3 with 4 and 3 bands (float64; complex factors (-i)^3 and (-i)^2)
+  G5 resnet50_hf.npz  NOT from the reference (its ResNet50 lives in an un-vendored third-party file): pool5 features of an
+                    INDEPENDENT third-party implementation of the same Caffe-style graph -- Hugging Face transformers
+                    ResNetModel(downsample_in_bottleneck=True), pooler swapped for MaxPool2d(3, 2, 0, ceil_mode=True) --
+                    loaded with the build's deterministic weights; pins the executor's wiring (stride placement,
+                    projection shortcuts, BN folding, pooling), not the unavailable checkpoint
   G7 sampler.npz    Snippet_Sampler.seq_ranges for N in {10,64,100,128,309} and the 13-frame window
                     ids decoded from constant-valued BMPs, + one textured BMP pass pinning
                     convert('L') + Lanczos 112->48 + /255
@@ -210,6 +215,46 @@ def g7_sampler(ref):
     print("G7", {k: v.shape for k, v in out.items()})
 
 
+def resnet_images(n, seed):
+    """[n,3,224,224] in the extractor's input convention (255*x - mean, utils/model_utils.py:36-39)."""
+    x = weights.det_uniform("resnet.img", (n, 3, 224, 224), 0.0, 1.0, seed)
+    return (x * np.float32(255.0) - np.asarray(weights.RESNET50_MEAN, dtype=np.float32)[None, :, None, None]).astype(np.float32)
+
+
+def g5_resnet50_hf():
+    import transformers
+    from transformers import ResNetConfig, ResNetModel
+    sd = weights.make_resnet50_state_dict(seed=0)
+    model = ResNetModel(ResNetConfig(downsample_in_bottleneck=True)).eval()
+    model.embedder.pooler = torch.nn.MaxPool2d(kernel_size=3, stride=2, padding=0, ceil_mode=True)   # pool1_3x3_s2 (Caffe)
+    hf = {}
+
+    def put(dst, src):
+        hf[dst + ".convolution.weight"] = torch.from_numpy(sd[src + ".weight"])
+        for k in ("weight", "bias", "running_mean", "running_var"):
+            hf[dst + ".normalization." + k] = torch.from_numpy(sd[src + "_bn." + k])
+
+    put("embedder.embedder", "conv1_7x7_s2")
+    for si, (stage, blocks, _, _, _) in enumerate(weights.RESNET50_STAGES):
+        for b in range(1, blocks + 1):
+            pre, dst = "conv%d_%d_" % (stage, b), "encoder.stages.%d.layers.%d" % (si, b - 1)
+            if b == 1:
+                put(dst + ".shortcut", pre + "1x1_proj")
+            put(dst + ".layer.0", pre + "1x1_reduce")
+            put(dst + ".layer.1", pre + "3x3")
+            put(dst + ".layer.2", pre + "1x1_increase")
+    missing, unexpected = model.load_state_dict(hf, strict=False)
+    assert not unexpected and all(k.endswith("num_batches_tracked") for k in missing), (missing, unexpected)
+    out = {"transformers_version": transformers.__version__, "weight_seed": 0}
+    for prec, dt in (("f32", torch.float32), ("f64", torch.float64)):
+        m = model.to(dt)
+        with torch.no_grad():
+            y = m(torch.from_numpy(resnet_images(2, 7)).to(dt)).pooler_output     # [2,2048,1,1] = AdaptiveAvgPool of stage 4
+        out["pool5_" + prec] = y.reshape(2, 2048).numpy()
+    print("G5", out["pool5_f32"].shape, np.abs(out["pool5_f32"]).max(), np.abs(out["pool5_f32"] - out["pool5_f64"]).max())
+    np.savez_compressed(os.path.join(HERE, "resnet50_hf.npz"), **out)
+
+
 SCF_FULL_CASES = [
     # tag, size, height, nbands, n_images, seed, stored dtype
     ("a", 96, 4, 2, 1, 8, np.float32),
@@ -235,6 +280,10 @@ def g8_scfpyr_full(ref):
 
 
 if __name__ == "__main__":
+    if sys.argv[1:] in ([], ["g5"]):
+        g5_resnet50_hf()   # before ref_shim.load(): its torchvision stub confuses transformers' optional-dependency probe
+        if sys.argv[1:]:
+            sys.exit(0)
     ref = ref_shim.load()
     if sys.argv[1:] == ["g8"]:
         g8_scfpyr_full(ref)

@@ -227,6 +227,27 @@ def test_resnet50_pool5_vs_oracle(resnet, oracle, dev):
     np.testing.assert_array_equal(got4, got)
 
 
+def test_resnet50_against_independent_third_party_implementation(resnet, golden, dev):
+    """HIP trunk vs Hugging Face transformers' ResNetModel outputs (tests/golden/resnet50_hf.npz, float64 run) on the
+    same deterministic weights: Winograd default and the direct form."""
+    g = golden("resnet50_hf")
+    assert int(g["weight_seed"]) == 0   # the `resnet` fixture's weights
+    x = weights.det_uniform("resnet.img", (2, 3, 224, 224), 0.0, 1.0, 7)
+    x = (x * np.float32(255.0) - np.asarray(weights.RESNET50_MEAN, dtype=np.float32)[None, :, None, None]).astype(np.float32)
+    want = g["pool5_f64"]
+    scale = np.abs(want).max()
+    xt = torch.from_numpy(x).to(dev)
+    try:
+        for mode in (4, 0):
+            resnet.set_winograd(mode)
+            got = resnet.get_vec(xt).cpu().numpy()
+            mx, mean = np.abs(got - want).max() / scale, np.abs(got - want).mean() / scale
+            print("vs HF ResNetModel, winograd %d: max rel %.2e mean rel %.2e" % (mode, mx, mean))
+            assert mx < POOL5_RTOL * 10 and mean < POOL5_RTOL, (mode, mx, mean)
+    finally:
+        resnet.set_winograd(True)
+
+
 def test_resnet50_winograd_and_direct_paths_agree(resnet, oracle, dev):
     """conv3_x..conv5_x 3x3 layers: Winograd F(4x4,3x3) (default), F(2x2,3x3) and the direct implicit-GEMM form, each
     against the oracle's direct fp32 convolution."""
