@@ -98,6 +98,12 @@ int mm_phase_extract(mm_pyramid_t* h, const float* coeff, const int32_t* ids,
                      int64_t img_stride, int64_t band_stride, int64_t J, int P, int W,
                      float* out, int out_nhwc, int out_cstride, int out_coffset, void* stream);
 
+/* extract() for ANY configuration (other band counts, plane sizes, window lengths than api/tester.py's):
+ * coeff device f32 [planes, P, R, C, 2] (planes = batch*nbands, the reference's view at :97-98) ->
+ * out [planes, P-1, R, C].  Same arithmetic as mm_phase_extract, generic and slower; R*C <= 4096, P >= 2,
+ * otherwise MM_ERR_UNSUPPORTED.  Needs no handle (the Gaussian taps are compile-time constants). */
+int mm_phase_extract_generic(const float* coeff, int64_t planes, int P, int R, int C, float* out, void* stream);
+
 /* Fused, de-duplicated driver for one batch of frames (the build's fast path): pyramid once
  * per unique frame, then J windows gathered through window ids (snippet_sampler.py:144-152).
  * frames [n,size,size]; ids int32 [J*13] in [0,n).  Outputs as in mm_phase_extract for W=size

@@ -1,0 +1,125 @@
+// Generic Phase_Difference_Extractor.extract (api/phase_difference_extractor.py:93-134) for any plane size up to 4096
+// pixels, any window length and any number of bands: the same arithmetic as phase_window.hip (atan2 / magnitude + 1e-10,
+// fmod unwrap over time, amplitude-weighted separable 11-tap blur with zero padding, temporal difference, spatial-mean
+// removal, clamp to +-5 pi), written for generality instead of speed.  The inference pipeline never comes here: it is
+// what makes the drop-in class usable with other constructor arguments than api/tester.py's (height / nbands / levels /
+// frame size / window length), together with the general pyramid of scfpyr.hip.
+#include "mm_common.h"
+#include "phase_math.h"
+
+namespace mm {
+namespace {
+
+constexpr int GTAP = 11, GR = 5, GNT = 256, GMAXPP = 16;   // 16 pixels per thread x 256 threads = 4096 pixels
+
+__device__ constexpr float g_gauss[GTAP] = {0.043936934322118759f, 0.1353352814912796f, 0.32465246319770813f,
+                                            0.60653066635131836f,  0.88249689340591431f, 1.0f,
+                                            0.88249689340591431f,  0.60653066635131836f, 0.32465246319770813f,
+                                            0.1353352814912796f,   0.043936934322118759f};
+
+// coeff [planes][P][R][C][2] -> out [planes][P-1][R][C]; one workgroup per plane set (b, band)
+__global__ void __launch_bounds__(GNT)
+phase_extract_generic_kernel(const float* __restrict__ coeff, float* __restrict__ out, int P, int R, int C) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int npix = R * C;
+    float* in_num = sm;
+    float* in_den = sm + npix;
+    float* tmp_num = sm + 2 * npix;
+    float* tmp_den = sm + 3 * npix;
+    __shared__ float red[GNT / 64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float* cp = coeff + (size_t)blockIdx.x * P * npix * 2;
+    float* op = out + (size_t)blockIdx.x * (P - 1) * npix;
+    const float LIM = 5.f * 3.14159265358979323846f;
+    float prev_ph[GMAXPP], cum[GMAXPP], prev_blur[GMAXPP], dcur[GMAXPP];
+    for (int p = 0; p < P; ++p) {
+#pragma unroll
+        for (int k = 0; k < GMAXPP; ++k) {
+            const int i = tid + k * GNT;
+            if (i < npix) {
+                const float2 c = reinterpret_cast<const float2*>(cp + (size_t)p * npix * 2)[i];
+                float ph, mag;
+                to_polar(c.x, c.y, ph, mag);
+                float up = ph;
+                if (p == 0) cum[k] = 0.f;
+                else up = unwrap_step(ph, prev_ph[k], cum[k]);
+                prev_ph[k] = ph;
+                in_num[i] = mag * up;
+                in_den[i] = mag;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < GMAXPP; ++k) {   // blur along the last dimension
+            const int i = tid + k * GNT;
+            if (i < npix) {
+                const int y = i / C, x = i - y * C;
+                float sn = 0.f, sd = 0.f;
+#pragma unroll
+                for (int t = 0; t < GTAP; ++t) {
+                    const int xx = x + t - GR;
+                    const bool ok = xx >= 0 && xx < C;
+                    sn = fmaf(g_gauss[t], ok ? in_num[y * C + xx] : 0.f, sn);
+                    sd = fmaf(g_gauss[t], ok ? in_den[y * C + xx] : 0.f, sd);
+                }
+                tmp_num[i] = sn;
+                tmp_den[i] = sd;
+            }
+        }
+        __syncthreads();
+        float part = 0.f;
+#pragma unroll
+        for (int k = 0; k < GMAXPP; ++k) {   // blur along the first dimension, ratio, temporal difference
+            const int i = tid + k * GNT;
+            if (i < npix) {
+                const int y = i / C, x = i - y * C;
+                float sn = 0.f, sd = 0.f;
+#pragma unroll
+                for (int t = 0; t < GTAP; ++t) {
+                    const int yy = y + t - GR;
+                    const bool ok = yy >= 0 && yy < R;
+                    sn = fmaf(g_gauss[t], ok ? tmp_num[yy * C + x] : 0.f, sn);
+                    sd = fmaf(g_gauss[t], ok ? tmp_den[yy * C + x] : 0.f, sd);
+                }
+                const float blur = sn / sd;
+                if (p > 0) {
+                    dcur[k] = blur - prev_blur[k];
+                    part += dcur[k];
+                }
+                prev_blur[k] = blur;
+            }
+        }
+        if (p > 0) {   // spatial mean of this difference plane, then mean removal + clamp (:130-133)
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) part += __shfl_down(part, off, 64);
+            if (lane == 0) red[wave] = part;
+            __syncthreads();
+            float s = 0.f;
+#pragma unroll
+            for (int w = 0; w < GNT / 64; ++w) s += red[w];
+            const float mean = s / (float)npix;
+#pragma unroll
+            for (int k = 0; k < GMAXPP; ++k) {
+                const int i = tid + k * GNT;
+                if (i < npix) op[(size_t)(p - 1) * npix + i] = fminf(fmaxf(dcur[k] - mean, -LIM), LIM);
+            }
+        }
+        __syncthreads();   // red[] and the LDS planes are rewritten by the next frame
+    }
+}
+
+}  // namespace
+}  // namespace mm
+
+extern "C" int mm_phase_extract_generic(const float* coeff, int64_t planes, int P, int R, int C, float* out, void* stream) {
+    if (planes < 0 || P < 2 || R <= 0 || C <= 0 || (planes > 0 && (!coeff || !out))) return MM_ERR_INVALID_ARG;
+    if ((int64_t)R * C > (int64_t)mm::GNT * mm::GMAXPP || planes > 0x7fffffff) return MM_ERR_UNSUPPORTED;
+    if (planes == 0) return MM_OK;
+    const size_t lds = (size_t)4 * R * C * sizeof(float);
+    MM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(mm::phase_extract_generic_kernel),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(mm::phase_extract_generic_kernel, dim3((unsigned)planes), dim3(mm::GNT), lds, (hipStream_t)stream, coeff, out,
+                       P, R, C);
+    MM_LAUNCH_CHECK();
+    return MM_OK;
+}

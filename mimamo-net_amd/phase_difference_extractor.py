@@ -13,10 +13,11 @@ from . import _lib
 
 class Phase_Difference_Extractor(object):
     def __init__(self, height=5, nbands=4, scale_factor=2, extract_level=1, visualize=False):
-        """Arguments as api/phase_difference_extractor.py:7-37.  This build implements the single
-        configuration the reference's Tester uses (api/tester.py:28-32): height=4, nbands=2,
-        scale_factor=2 on 48x48 inputs; other values raise NotImplementedError at the first call
-        (RuntimeError 'image too small' keeps the reference's meaning, SCFpyr_PyTorch.py:90-91)."""
+        """Arguments as api/phase_difference_extractor.py:7-37.  The configuration the reference's Tester uses
+        (api/tester.py:28-32: height=4, nbands=2, scale_factor=2, levels 1/2, 48x48 frames, 13-frame windows) runs on
+        the fused hot-path kernels; every other configuration goes through the general pyramid (csrc/scfpyr.hip,
+        square frames up to 48x48 with symmetry, 96x96 without) and the generic extract kernel (csrc/phase_generic.hip).
+        RuntimeError 'image too small' keeps the reference's meaning (SCFpyr_PyTorch.py:90-91)."""
         if visualize:
             raise NotImplementedError("visualize=True is a debug path of the reference (matplotlib); out of scope")
         self.height = height
@@ -27,6 +28,15 @@ class Phase_Difference_Extractor(object):
         self._handle = None
         self._size = None
         self._ids_cache = {}
+        self._general = None   # SCFpyr_PyTorch for configurations outside the fused kernels
+
+    def _levels(self):
+        return [self.extract_level] if isinstance(self.extract_level, int) else list(self.extract_level)
+
+    def _fused(self, W, symmetry=True):
+        """True when the hot-path kernels (pyramid.hip / phase_window.hip) implement this configuration."""
+        return (symmetry and W == 48 and (self.height, self.nbands, self.scale_factor) == (4, 2, 2)
+                and all(lv in (1, 2) for lv in self._levels()))
 
     # -- native handle -------------------------------------------------------------------
     def _get(self, size):
@@ -65,15 +75,12 @@ class Phase_Difference_Extractor(object):
         """im_batch [B, P, W, H] -> coefficients [B, nbands, P, W_l, H_l, 2] (a list when extract_level is
         a list) -- api/phase_difference_extractor.py:38-87."""
         self._check_input(im_batch, 4, "im_batch")
-        if not symmetry:
-            raise NotImplementedError("symmetry=False is never used by the inference path")
         B, P, W, H = im_batch.shape
         assert W == H, "square frames only (SCFpyr_PyTorch.py:87 swaps height/width)"
+        if not self._fused(W, symmetry):
+            return self._build_pyramid_general(im_batch.contiguous(), symmetry)
         h = self._get(W)
-        levels = [self.extract_level] if isinstance(self.extract_level, int) else list(self.extract_level)
-        for lv in levels:
-            if lv not in (1, 2):
-                raise NotImplementedError("extract_level %r: only pyramid list items 1 and 2 are produced" % (lv,))
+        levels = self._levels()
         x = im_batch.contiguous()
         c1 = torch.empty((B, self.nbands, P, W, H, 2), dtype=torch.float32, device=x.device)
         c2 = torch.empty((B, self.nbands, P, W // 2, H // 2, 2), dtype=torch.float32, device=x.device)
@@ -82,6 +89,30 @@ class Phase_Difference_Extractor(object):
         out = [c1 if lv == 1 else c2 for lv in levels]
         return out[0] if isinstance(self.extract_level, int) else out
 
+    def _build_pyramid_general(self, x, symmetry):
+        """Any other configuration: mirror (index-only, torch ops), the general steerable pyramid, then the reference's
+        stack / view / permute / quadrant crop (:71-86)."""
+        from .scfpyr import SCFpyr_PyTorch
+        B, P, W, H = x.shape
+        im = x.view(B * P, 1, W, H)
+        if symmetry:   # symmetric_extension_batch, api/utils/phase_utils.py:116-129
+            top = torch.cat([im, im.flip(-1)], dim=-1)
+            im = torch.cat([top, top.flip(-2)], dim=-2).contiguous()
+        if self._general is None or self._general.device != x.device:
+            self._general = SCFpyr_PyTorch(self.height, self.nbands, self.scale_factor, device=x.device, precision=32)
+        coeff = self._general.build(im)
+        outs = []
+        for lv in self._levels():
+            bands = coeff[lv]
+            assert isinstance(bands, list)   # extract_coeff_level (:90): residual levels are not lists
+            c = torch.stack(bands, 0)         # [nbands, B*P, w, h, 2]
+            w, h = c.shape[-3], c.shape[-2]
+            c = c.view(len(bands), B, P, w, h, 2).permute(1, 0, 2, 3, 4, 5).contiguous()
+            if symmetry:
+                c = c[..., : w // 2, : h // 2, :]
+            outs.append(c)
+        return outs[0] if isinstance(self.extract_level, int) else outs
+
     def extract(self, coeff_batch):
         """coeff [B, nbands, P, W, H, 2] -> phase differences [B, nbands, P-1, W, H]
         (api/phase_difference_extractor.py:93-134)."""
@@ -89,10 +120,14 @@ class Phase_Difference_Extractor(object):
             raise ValueError("extract() takes the coefficients of ONE level")
         self._check_input(coeff_batch, 6, "coeff_batch")
         B, nb, P, W, H, two = coeff_batch.shape
-        assert two == 2 and W == H and nb == self.nbands
-        size = self._size if self._size is not None else (W if W >= 48 else 2 * W)
-        h = self._get(size)
+        assert two == 2
         c = coeff_batch.contiguous()
+        out = torch.empty((B, nb, P - 1, W, H), dtype=torch.float32, device=c.device)
+        if not (W == H and W in (48, 24) and nb == 2 and P == 13 and (self.height, self.nbands, self.scale_factor) == (4, 2, 2)):
+            rc = _lib.lib().mm_phase_extract_generic(_lib.ptr(c), B * nb, P, W, H, _lib.ptr(out), _lib.current_stream())
+            _lib.check(rc, "mm_phase_extract_generic")
+            return out
+        h = self._get(self._size if self._size is not None else 48)
         key = (B, P, nb, str(c.device))
         ids = self._ids_cache.get(key)
         if ids is None:
@@ -100,7 +135,6 @@ class Phase_Difference_Extractor(object):
             ids = (torch.arange(B, device=c.device, dtype=torch.int32)[:, None] * (nb * P)
                    + torch.arange(P, device=c.device, dtype=torch.int32)[None, :]).contiguous()
             self._ids_cache = {key: ids}
-        out = torch.empty((B, nb, P - 1, W, H), dtype=torch.float32, device=c.device)
         plane = W * H * 2
         rc = _lib.lib().mm_phase_extract(h, _lib.ptr(c), _lib.ptr(ids), plane, P * plane, B, P, W, _lib.ptr(out),
                                          0, 0, 0, _lib.current_stream())

@@ -21,6 +21,9 @@ arguments and the reference's outputs are saved.
                     ResNetModel(downsample_in_bottleneck=True), pooler swapped for MaxPool2d(3, 2, 0, ceil_mode=True) --
                     loaded with the build's deterministic weights; pins the executor's wiring (stride placement,
                     projection shortcuts, BN folding, pooling), not the unavailable checkpoint
+  G9 phase_generic.npz  Phase_Difference_Extractor with OTHER constructor arguments than api/tester.py's: (height 3, 4 bands,
+                    level 1, 5 textured 32x32 frames, symmetry) and (height 3, 2 bands, level [1], 3 frames, symmetry=False):
+                    build_pyramid -> extract outputs
   G7 sampler.npz    Snippet_Sampler.seq_ranges for N in {10,64,100,128,309} and the 13-frame window
                     ids decoded from constant-valued BMPs, + one textured BMP pass pinning
                     convert('L') + Lanczos 112->48 + /255
@@ -255,6 +258,25 @@ def g5_resnet50_hf():
     np.savez_compressed(os.path.join(HERE, "resnet50_hf.npz"), **out)
 
 
+def g9_phase_generic(ref):
+    out = {}
+    x = torch.from_numpy(synthetic.textured_gray(5, 32, seed=31))[None]            # [1,5,32,32]
+    pde = ref.Phase_Difference_Extractor(3, 4, 2, 1, False)
+    torch.set_default_dtype(torch.float32)
+    c = pde.build_pyramid(x)                                                        # [1,4,5,32,32,2]
+    out["a_coeff"] = c.numpy()
+    out["a_diff"] = pde.extract(c).numpy()                                          # [1,4,4,32,32]
+    x2 = torch.from_numpy(synthetic.textured_gray(3, 32, seed=32))[None]
+    pde2 = ref.Phase_Difference_Extractor(3, 2, 2, [1], False)
+    torch.set_default_dtype(torch.float32)
+    c2 = pde2.build_pyramid(x2, symmetry=False)                                     # [[1,2,3,32,32,2]]
+    out["b_coeff"] = c2[0].numpy()
+    out["b_diff"] = pde2.extract(c2[0]).numpy()
+    torch.set_default_dtype(torch.float32)
+    print("G9", {k: v.shape for k, v in out.items()})
+    np.savez_compressed(os.path.join(HERE, "phase_generic.npz"), **out)
+
+
 SCF_FULL_CASES = [
     # tag, size, height, nbands, n_images, seed, stored dtype
     ("a", 96, 4, 2, 1, 8, np.float32),
@@ -285,6 +307,9 @@ if __name__ == "__main__":
         if sys.argv[1:]:
             sys.exit(0)
     ref = ref_shim.load()
+    if sys.argv[1:] == ["g9"]:
+        g9_phase_generic(ref)
+        sys.exit(0)
     if sys.argv[1:] == ["g8"]:
         g8_scfpyr_full(ref)
         sys.exit(0)
@@ -295,4 +320,5 @@ if __name__ == "__main__":
     g4_head(ref)
     g7_sampler(ref)
     g8_scfpyr_full(ref)
+    g9_phase_generic(ref)
     os.system("ls -la %s" % HERE)

@@ -155,8 +155,10 @@ def test_error_behaviour(pkg, dev):
     x = torch.zeros(1, 13, 48, 48, device=dev)
     with pytest.raises(RuntimeError, match="image too small"):
         Phase_Difference_Extractor(5, 2, 2, [1, 2]).build_pyramid(x)  # SCFpyr_PyTorch.py:90-91
-    with pytest.raises(NotImplementedError):
-        Phase_Difference_Extractor(4, 4, 2, [1, 2]).build_pyramid(x)
+    with pytest.raises(NotImplementedError):   # mirrored side 128 > 96: beyond the general pyramid's LDS-resident transform
+        Phase_Difference_Extractor(4, 2, 2, [1, 2]).build_pyramid(torch.zeros(1, 2, 64, 64, device=dev))
+    with pytest.raises(AssertionError):        # level 0 is the hi-pass residual, not a list of bands (:90)
+        Phase_Difference_Extractor(4, 4, 2, [0]).build_pyramid(x)
     with pytest.raises(RuntimeError):
         Phase_Difference_Extractor(4, 2, 2, [1, 2]).build_pyramid(x.cpu())
     with pytest.raises(ValueError):
@@ -222,3 +224,46 @@ def test_scfpyr_errors(pkg, dev):
     assert [tuple(t.shape) if not isinstance(t, list) else [tuple(u.shape) for u in t]
             for t in pyr.build(torch.zeros(0, 1, 96, 96, device=dev))] == \
         [(0, 96, 96), [(0, 96, 96, 2)] * 2, [(0, 48, 48, 2)] * 2, (0, 24, 24)]
+
+
+def test_other_constructor_arguments_golden(pkg, golden, oracle, dev):
+    """Configurations outside api/tester.py's (general pyramid + generic extract kernel) vs the real reference."""
+    from mimamo_net_amd.phase_difference_extractor import Phase_Difference_Extractor
+    g = golden("phase_generic")
+    # (a) height 3, 4 bands, level 1 (int), symmetry, 5 frames of 32x32
+    pde = Phase_Difference_Extractor(3, 4, 2, 1, False)
+    c = pde.build_pyramid(torch.from_numpy(synthetic.textured_gray(5, 32, seed=31))[None].to(dev))
+    assert tuple(c.shape) == (1, 4, 5, 32, 32, 2)
+    assert (c.cpu().numpy() - g["a_coeff"]).__abs__().max() < COEFF_ATOL
+    d = pde.extract(c)
+    mx, p9999, flips = _phase_err(d.cpu().numpy(), g["a_diff"])
+    assert mx < PHASE_ATOL and p9999 < PHASE_P9999 and flips <= 2, (mx, p9999, flips)
+    # the generic kernel on the reference's own coefficients isolates it from the pyramid
+    d2 = pde.extract(torch.from_numpy(g["a_coeff"]).to(dev))
+    assert np.abs(d2.cpu().numpy() - g["a_diff"]).max() < 2e-5
+    # (b) height 3, 2 bands, level list, symmetry=False, 3 frames
+    pde2 = Phase_Difference_Extractor(3, 2, 2, [1], False)
+    c2 = pde2.build_pyramid(torch.from_numpy(synthetic.textured_gray(3, 32, seed=32))[None].to(dev), symmetry=False)
+    assert isinstance(c2, list) and tuple(c2[0].shape) == (1, 2, 3, 32, 32, 2)
+    assert np.abs(c2[0].cpu().numpy() - g["b_coeff"]).max() < COEFF_ATOL
+    assert np.abs(pde2.extract(c2[0]).cpu().numpy() - g["b_diff"]).max() < 2e-5
+
+
+def test_generic_extract_equals_fused_kernel(pde, oracle, dev):
+    """Same coefficients through the fused window kernel (P = 13) and the generic kernel: same arithmetic, the spatial
+    mean is the only differently-ordered reduction."""
+    from mimamo_net_amd import _lib
+    x = torch.from_numpy(synthetic.textured_gray(13, 48, seed=91))[None].to(dev)
+    c1, c2 = pde.build_pyramid(x)
+    for c in (c1, c2):
+        fused = pde.extract(c)
+        B, nb, P, W, H, _ = c.shape
+        gen = torch.empty_like(fused)
+        rc = _lib.lib().mm_phase_extract_generic(_lib.ptr(c.contiguous()), B * nb, P, W, H, _lib.ptr(gen), _lib.current_stream())
+        assert rc == 0
+        assert (fused - gen).abs().max() < 2e-6
+    # a window length the fused kernel does not implement goes to the generic kernel through the same method
+    d7 = pde.extract(c1[:, :, :7].contiguous())
+    want = oracle.extract(c1[:, :, :7].cpu().numpy())
+    mx, p9999, flips = _phase_err(d7.cpu().numpy(), want)
+    assert tuple(d7.shape) == (1, 2, 6, 48, 48) and mx < PHASE_ATOL and p9999 < PHASE_P9999 and flips <= 2
