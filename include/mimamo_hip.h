@@ -118,8 +118,8 @@ int mm_phase_diff_frames(mm_pyramid_t* h, const float* frames, int64_t n, const 
  * General complex steerable pyramid -- replaces `SCFpyr_PyTorch(height, nbands, scale_factor,
  * device, precision).build(im_batch)` (api/steerable/SCFpyr_PyTorch.py:51-125 and
  * _build_levels :127-208) with its FULL return list: hi-pass residual, every oriented band of every
- * level, low-pass residual.  Arbitrary (non-mirrored) square images, even side <= 96 whose level
- * grids stay even, height >= 2, 2 <= nbands <= 16; otherwise MM_ERR_UNSUPPORTED;
+ * level, low-pass residual.  Arbitrary (non-mirrored) square images, even side <= 256 whose level
+ * grids stay even (each 2-D transform's intermediate lives in LDS up to side 96, in the workspace above), height >= 2, 2 <= nbands <= 16; otherwise MM_ERR_UNSUPPORTED;
  * `height > floor(log2(size)) - 2` returns MM_ERR_TOO_SMALL (the reference's RuntimeError, :90-91).
  * The inference hot path does not go through here (mm_pyramid_* exploits the mirrored input).
  * ------------------------------------------------------------------------------------- */

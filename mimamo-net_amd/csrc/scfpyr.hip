@@ -1,6 +1,7 @@
 // General complex steerable pyramid: the whole return list of SCFpyr_PyTorch.build
 // (api/steerable/SCFpyr_PyTorch.py:70-208) -- hi-pass residual, every oriented band of every level, low-pass
-// residual -- for arbitrary (non-mirrored) square images up to 96x96, any height / number of bands, fp32 or fp64 I/O.
+// residual -- for arbitrary (non-mirrored) square images up to 256x256 (the intermediate of each 2-D transform lives in
+// LDS up to 96x96, in a global scratch above), any height / number of bands, fp32 or fp64 I/O.
 //
 // This is the API-completeness path, not the hot path: the inference pipeline uses pyramid.hip, which exploits the
 // mirror symmetry of its input and keeps only the coefficients the phase stage consumes.  Here every transform is a
@@ -30,14 +31,15 @@ namespace mm {
 namespace {
 
 constexpr int kScfThreads = 256;
-constexpr int kScfMaxSide = 96;  // LDS: side^2 complex float64 = 147 456 B at 96
+constexpr int kScfLdsSide = 96;   // LDS-resident intermediate: side^2 complex float64 = 147 456 B at 96
+constexpr int kScfMaxSide = 256;  // above kScfLdsSide the intermediate goes through a global scratch (L2-resident)
 
 template <typename TIn>
 __global__ __launch_bounds__(kScfThreads) void scf_forward_kernel(const TIn* __restrict__ im, double2* __restrict__ F,
-                                                                  const double2* __restrict__ tw, int n0) {
+                                                                  const double2* __restrict__ tw, int n0, double2* scratch) {
     extern __shared__ __attribute__((aligned(16))) double2 sm[];
-    double2* X1 = sm;            // [n0][n0] row transforms
-    double2* w = sm + n0 * n0;   // [n0]
+    double2* w = sm;                                                                     // [n0]
+    double2* X1 = scratch ? scratch + (size_t)blockIdx.x * n0 * n0 : sm + n0;           // [n0][n0] row transforms
     for (int k = threadIdx.x; k < n0; k += kScfThreads) w[k] = tw[k];
     __syncthreads();
     const TIn* x = im + (size_t)blockIdx.x * n0 * n0;
@@ -77,10 +79,10 @@ __global__ __launch_bounds__(kScfThreads) void scf_forward_kernel(const TIn* __r
 template <typename TOut>
 __global__ __launch_bounds__(kScfThreads) void scf_inverse_kernel(const double2* __restrict__ F, const double2* __restrict__ T,
                                                                   const double2* __restrict__ tw, TOut* __restrict__ out,
-                                                                  int n0, int m, int is_complex) {
+                                                                  int n0, int m, int is_complex, double2* scratch) {
     extern __shared__ __attribute__((aligned(16))) double2 sm[];
-    double2* Y = sm;           // [m][m]
-    double2* w = sm + m * m;   // [m]   e^{+2 pi i k/m} = tw[k * n0/m]
+    double2* w = sm;                                                                 // [m]   e^{+2 pi i k/m} = tw[k * n0/m]
+    double2* Y = scratch ? scratch + (size_t)blockIdx.x * m * m : sm + m;           // [m][m]
     const int step = n0 / m;
     for (int k = threadIdx.x; k < m; k += kScfThreads) w[k] = tw[k * step];
     __syncthreads();
@@ -233,7 +235,8 @@ int mm_scfpyr_output_info(const mm_scfpyr_t* h, int index, int* side, int* is_co
 
 int64_t mm_scfpyr_workspace_bytes(const mm_scfpyr_t* h, int64_t n) {
     if (!h || n < 0) return MM_ERR_INVALID_ARG;
-    return n * (int64_t)h->size * h->size * (int64_t)sizeof(double2);
+    // spectrum, plus (sides above the LDS-resident limit) one intermediate plane per image
+    return n * (int64_t)h->size * h->size * (int64_t)sizeof(double2) * (h->size > mm::kScfLdsSide ? 2 : 1);
 }
 
 int mm_scfpyr_build(const mm_scfpyr_t* h, const void* images, int precision, int64_t n, void* const* outputs,
@@ -248,28 +251,33 @@ int mm_scfpyr_build(const mm_scfpyr_t* h, const void* images, int precision, int
     hipStream_t s = (hipStream_t)stream;
     double2* F = (double2*)workspace;
     const int n0 = h->size;
-    const size_t lds_f = ((size_t)n0 * n0 + n0) * sizeof(double2);
+    double2* scratch = n0 > mm::kScfLdsSide ? F + (size_t)n * n0 * n0 : nullptr;   // [n][n0][n0], reused by every launch
+    auto lds_bytes = [&](int m) { return ((scratch ? 0 : (size_t)m * m) + m) * sizeof(double2); };
+    const size_t lds_f = lds_bytes(n0);
+    const size_t lds_max = ((size_t)mm::kScfLdsSide * mm::kScfLdsSide + mm::kScfMaxSide) * sizeof(double2);   // 151 552 B
     const dim3 grid((unsigned)n), block(mm::kScfThreads);
     int rc;
     if (precision == 32) {
         if ((rc = mm::raise_lds(mm::scf_forward_kernel<float>, lds_f)) != MM_OK) return rc;
-        hipLaunchKernelGGL(mm::scf_forward_kernel<float>, grid, block, lds_f, s, (const float*)images, F, h->d_twiddle, n0);
+        hipLaunchKernelGGL(mm::scf_forward_kernel<float>, grid, block, lds_f, s, (const float*)images, F, h->d_twiddle, n0, scratch);
     } else {
         if ((rc = mm::raise_lds(mm::scf_forward_kernel<double>, lds_f)) != MM_OK) return rc;
-        hipLaunchKernelGGL(mm::scf_forward_kernel<double>, grid, block, lds_f, s, (const double*)images, F, h->d_twiddle, n0);
+        hipLaunchKernelGGL(mm::scf_forward_kernel<double>, grid, block, lds_f, s, (const double*)images, F, h->d_twiddle, n0, scratch);
     }
     MM_LAUNCH_CHECK();
     for (int i = 0; i < h->n_out; ++i) {
         const int m = h->side[i];
-        const size_t lds_i = ((size_t)m * m + m) * sizeof(double2);
+        // a level whose grid fits keeps its intermediate in LDS even when the full-size levels do not
+        double2* sc = m > mm::kScfLdsSide ? scratch : nullptr;
+        const size_t lds_i = ((sc ? 0 : (size_t)m * m) + m) * sizeof(double2);
         if (precision == 32) {
-            if ((rc = mm::raise_lds(mm::scf_inverse_kernel<float>, lds_f)) != MM_OK) return rc;
+            if ((rc = mm::raise_lds(mm::scf_inverse_kernel<float>, lds_max)) != MM_OK) return rc;
             hipLaunchKernelGGL(mm::scf_inverse_kernel<float>, grid, block, lds_i, s, F, h->d_table[i], h->d_twiddle,
-                               (float*)outputs[i], n0, m, h->is_complex[i]);
+                               (float*)outputs[i], n0, m, h->is_complex[i], sc);
         } else {
-            if ((rc = mm::raise_lds(mm::scf_inverse_kernel<double>, lds_f)) != MM_OK) return rc;
+            if ((rc = mm::raise_lds(mm::scf_inverse_kernel<double>, lds_max)) != MM_OK) return rc;
             hipLaunchKernelGGL(mm::scf_inverse_kernel<double>, grid, block, lds_i, s, F, h->d_table[i], h->d_twiddle,
-                               (double*)outputs[i], n0, m, h->is_complex[i]);
+                               (double*)outputs[i], n0, m, h->is_complex[i], sc);
         }
         MM_LAUNCH_CHECK();
     }

@@ -16,7 +16,8 @@ class Phase_Difference_Extractor(object):
         """Arguments as api/phase_difference_extractor.py:7-37.  The configuration the reference's Tester uses
         (api/tester.py:28-32: height=4, nbands=2, scale_factor=2, levels 1/2, 48x48 frames, 13-frame windows) runs on
         the fused hot-path kernels; every other configuration goes through the general pyramid (csrc/scfpyr.hip,
-        square frames up to 48x48 with symmetry, 96x96 without) and the generic extract kernel (csrc/phase_generic.hip).
+        square frames up to 128x128 with symmetry, 256x256 without) and the generic extract kernel
+        (csrc/phase_generic.hip, planes up to 4096 pixels).
         RuntimeError 'image too small' keeps the reference's meaning (SCFpyr_PyTorch.py:90-91)."""
         if visualize:
             raise NotImplementedError("visualize=True is a debug path of the reference (matplotlib); out of scope")

@@ -22,8 +22,8 @@ arguments and the reference's outputs are saved.
                     loaded with the build's deterministic weights; pins the executor's wiring (stride placement,
                     projection shortcuts, BN folding, pooling), not the unavailable checkpoint
   G9 phase_generic.npz  Phase_Difference_Extractor with OTHER constructor arguments than api/tester.py's: (height 3, 4 bands,
-                    level 1, 5 textured 32x32 frames, symmetry) and (height 3, 2 bands, level [1], 3 frames, symmetry=False):
-                    build_pyramid -> extract outputs
+                    level 1, 5 textured 32x32 frames, symmetry) and (height 3, 2 bands, level [1], 3 frames, symmetry=False),
+                    and the class defaults (height 5, 4 bands, level 1) on 64x64 frames: build_pyramid -> extract outputs
   G7 sampler.npz    Snippet_Sampler.seq_ranges for N in {10,64,100,128,309} and the 13-frame window
                     ids decoded from constant-valued BMPs, + one textured BMP pass pinning
                     convert('L') + Lanczos 112->48 + /255
@@ -272,6 +272,13 @@ def g9_phase_generic(ref):
     c2 = pde2.build_pyramid(x2, symmetry=False)                                     # [[1,2,3,32,32,2]]
     out["b_coeff"] = c2[0].numpy()
     out["b_diff"] = pde2.extract(c2[0]).numpy()
+    # (c) the class DEFAULTS (height 5, 4 bands, level 1) need >= 64x64 frames: mirrored side 128
+    x3 = torch.from_numpy(synthetic.textured_gray(3, 64, seed=33))[None]
+    pde3 = ref.Phase_Difference_Extractor()
+    torch.set_default_dtype(torch.float32)
+    c3 = pde3.build_pyramid(x3)                                                     # [1,4,3,64,64,2]
+    out["c_coeff_band0"] = c3[:, :1].numpy()
+    out["c_diff"] = pde3.extract(c3).numpy()                                        # [1,4,2,64,64]
     torch.set_default_dtype(torch.float32)
     print("G9", {k: v.shape for k, v in out.items()})
     np.savez_compressed(os.path.join(HERE, "phase_generic.npz"), **out)

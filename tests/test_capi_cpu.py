@@ -116,7 +116,7 @@ def test_scfpyr_config_errors(L):
     q = lambda *a: L.mm_scfpyr_host_table(*a, 0, None, ctypes.byref(side), ctypes.byref(cp))
     assert q(96, 5, 2, 2) == -2      # 5 > floor(log2 96) - 2 = 4: 'image too small' (SCFpyr_PyTorch.py:90-91)
     assert q(96, 4, 1, 2) == -3      # nbands = 1 never terminates in the reference (quirk Q7)
-    assert q(128, 4, 2, 2) == -3     # larger than the LDS-resident transform supports
+    assert q(128, 4, 2, 2) == 0 and q(258, 4, 2, 2) == -3     # up to 256 (global scratch above the LDS-resident 96)
     assert q(84, 4, 2, 2) == -3      # 84 -> 42 -> 21: an odd level grid (shifts differently; not supported)
     assert q(40, 3, 2, 2) == 0 and side.value == 40
     assert q(96, 4, 2, 2) == 0 and side.value == 96 and cp.value == 0

@@ -155,8 +155,8 @@ def test_error_behaviour(pkg, dev):
     x = torch.zeros(1, 13, 48, 48, device=dev)
     with pytest.raises(RuntimeError, match="image too small"):
         Phase_Difference_Extractor(5, 2, 2, [1, 2]).build_pyramid(x)  # SCFpyr_PyTorch.py:90-91
-    with pytest.raises(NotImplementedError):   # mirrored side 128 > 96: beyond the general pyramid's LDS-resident transform
-        Phase_Difference_Extractor(4, 2, 2, [1, 2]).build_pyramid(torch.zeros(1, 2, 64, 64, device=dev))
+    with pytest.raises(NotImplementedError):   # mirrored side 320 > 256: beyond the general pyramid
+        Phase_Difference_Extractor(4, 2, 2, [1, 2]).build_pyramid(torch.zeros(1, 2, 160, 160, device=dev))
     with pytest.raises(AssertionError):        # level 0 is the hi-pass residual, not a list of bands (:90)
         Phase_Difference_Extractor(4, 4, 2, [0]).build_pyramid(x)
     with pytest.raises(RuntimeError):
@@ -220,7 +220,7 @@ def test_scfpyr_errors(pkg, dev):
     with pytest.raises(RuntimeError, match="image too small"):
         SCFpyr_PyTorch(height=5, nbands=2, device=dev).build(torch.zeros(1, 1, 48, 48, device=dev))   # :90-91
     with pytest.raises(NotImplementedError):
-        SCFpyr_PyTorch(height=4, nbands=2, device=dev).build(torch.zeros(1, 1, 128, 128, device=dev))
+        SCFpyr_PyTorch(height=4, nbands=2, device=dev).build(torch.zeros(1, 1, 320, 320, device=dev))
     assert [tuple(t.shape) if not isinstance(t, list) else [tuple(u.shape) for u in t]
             for t in pyr.build(torch.zeros(0, 1, 96, 96, device=dev))] == \
         [(0, 96, 96), [(0, 96, 96, 2)] * 2, [(0, 48, 48, 2)] * 2, (0, 24, 24)]
@@ -247,6 +247,44 @@ def test_other_constructor_arguments_golden(pkg, golden, oracle, dev):
     assert isinstance(c2, list) and tuple(c2[0].shape) == (1, 2, 3, 32, 32, 2)
     assert np.abs(c2[0].cpu().numpy() - g["b_coeff"]).max() < COEFF_ATOL
     assert np.abs(pde2.extract(c2[0]).cpu().numpy() - g["b_diff"]).max() < 2e-5
+
+
+def test_class_defaults_on_64x64_frames_golden(pkg, golden, dev):
+    """Phase_Difference_Extractor() -- height 5, 4 bands, level 1 -- needs >= 64x64 frames; the mirrored 128x128 pyramid
+    runs with its transform intermediates in the global scratch (above the 96x96 LDS-resident limit)."""
+    from mimamo_net_amd.phase_difference_extractor import Phase_Difference_Extractor
+    g = golden("phase_generic")
+    pde = Phase_Difference_Extractor()
+    c = pde.build_pyramid(torch.from_numpy(synthetic.textured_gray(3, 64, seed=33))[None].to(dev))
+    assert tuple(c.shape) == (1, 4, 3, 64, 64, 2)
+    assert np.abs(c[:, :1].cpu().numpy() - g["c_coeff_band0"]).max() < COEFF_ATOL
+    mx, p9999, flips = _phase_err(pde.extract(c).cpu().numpy(), g["c_diff"])
+    assert mx < PHASE_ATOL and p9999 < PHASE_P9999 and flips <= 2, (mx, p9999, flips)
+    with pytest.raises(RuntimeError, match="image too small"):      # the same defaults on the Tester's 48x48 frames
+        pde.build_pyramid(torch.zeros(1, 3, 48, 48, device=dev))
+
+
+@pytest.mark.parametrize("precision", [32, 64])
+def test_scfpyr_large_side_vs_oracle(pkg, oracle, dev, precision):
+    """128x128 and 160x160 images (scratch-backed transforms; 160 -> 80 is an LDS-resident level inside a scratch-backed
+    pyramid) against the oracle's torch.fft restatement (itself pinned on three configurations, G8)."""
+    from mimamo_net_amd.scfpyr import SCFpyr_PyTorch
+    from mimamo_net_amd import weights
+    dt, ndt = (torch.float32, np.float32) if precision == 32 else (torch.float64, np.float64)
+    for size, height, nbands in ((128, 5, 4), (160, 4, 3)):
+        x = weights.det_uniform("scf.big%d" % size, (2, 1, size, size), 0.0, 1.0, 3).astype(ndt)
+        coeff = SCFpyr_PyTorch(height, nbands, 2, device=dev, precision=precision).build(torch.from_numpy(x).to(dev))
+        levels, hi, lo = oracle.pyramid_build(x[:, 0].astype(np.float64), height, nbands, dtype=np.float64, keep_residuals=True)
+        tol = 3e-7 if precision == 32 else 1e-12
+        def close(got, want):
+            assert tuple(got.shape) == want.shape, (got.shape, want.shape)
+            err = np.abs(got.double().cpu().numpy() - want).max()
+            assert err <= tol * max(1.0, np.abs(want).max()), (size, err)
+        close(coeff[0], hi)
+        close(coeff[-1], lo)
+        for l, c in enumerate(levels):
+            for b in range(nbands):
+                close(coeff[l + 1][b], np.stack([c[b].real, c[b].imag], -1))
 
 
 def test_generic_extract_equals_fused_kernel(pde, oracle, dev):
