@@ -101,8 +101,12 @@ int mm_phase_extract(mm_pyramid_t* h, const float* coeff, const int32_t* ids,
 /* extract() for ANY configuration (other band counts, plane sizes, window lengths than api/tester.py's):
  * coeff device f32 [planes, P, R, C, 2] (planes = batch*nbands, the reference's view at :97-98) ->
  * out [planes, P-1, R, C].  Same arithmetic as mm_phase_extract, generic and slower; R*C <= 4096, P >= 2,
- * otherwise MM_ERR_UNSUPPORTED.  Needs no handle (the Gaussian taps are compile-time constants). */
-int mm_phase_extract_generic(const float* coeff, int64_t planes, int P, int R, int C, float* out, void* stream);
+ * otherwise MM_ERR_UNSUPPORTED.  Needs no handle (the Gaussian taps are compile-time constants).
+ * denoised (optional, may be NULL): [planes, P, R, C], the amplitude-blurred unwrapped phase with its spatial
+ * mean removed -- what the training-side `Steerable_Pyramid_Phase.extract_phase(return_phase=True)` returns
+ * (Aff-wild-exps/utils.py:367-418). */
+int mm_phase_extract_generic(const float* coeff, int64_t planes, int P, int R, int C, float* out, float* denoised,
+                             void* stream);
 
 /* Fused, de-duplicated driver for one batch of frames (the build's fast path): pyramid once
  * per unique frame, then J windows gathered through window ids (snippet_sampler.py:144-152).

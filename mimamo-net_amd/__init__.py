@@ -10,6 +10,7 @@ __version__ = "0.1.0"
 _LAZY = {
     "Phase_Difference_Extractor": ".phase_difference_extractor",
     "SCFpyr_PyTorch": ".scfpyr",
+    "Steerable_Pyramid_Phase": ".phase_difference_extractor",
     "Resnet50_Extractor": ".resnet50_extractor",
     "Two_Stream_RNN": ".mimamo_net",
     "Tester": ".tester",

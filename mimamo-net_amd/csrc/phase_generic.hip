@@ -19,19 +19,21 @@ __device__ constexpr float g_gauss[GTAP] = {0.043936934322118759f, 0.13533528149
 
 // coeff [planes][P][R][C][2] -> out [planes][P-1][R][C]; one workgroup per plane set (b, band)
 __global__ void __launch_bounds__(GNT)
-phase_extract_generic_kernel(const float* __restrict__ coeff, float* __restrict__ out, int P, int R, int C) {
+phase_extract_generic_kernel(const float* __restrict__ coeff, float* __restrict__ out, float* __restrict__ den_out, int P, int R,
+                             int C) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int npix = R * C;
     float* in_num = sm;
     float* in_den = sm + npix;
     float* tmp_num = sm + 2 * npix;
     float* tmp_den = sm + 3 * npix;
-    __shared__ float red[GNT / 64];
+    __shared__ float red[GNT / 64], red2[GNT / 64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const float* cp = coeff + (size_t)blockIdx.x * P * npix * 2;
     float* op = out + (size_t)blockIdx.x * (P - 1) * npix;
     const float LIM = 5.f * 3.14159265358979323846f;
     float prev_ph[GMAXPP], cum[GMAXPP], prev_blur[GMAXPP], dcur[GMAXPP];
+    float* dp = den_out ? den_out + (size_t)blockIdx.x * P * npix : nullptr;
     for (int p = 0; p < P; ++p) {
 #pragma unroll
         for (int k = 0; k < GMAXPP; ++k) {
@@ -67,7 +69,7 @@ phase_extract_generic_kernel(const float* __restrict__ coeff, float* __restrict_
             }
         }
         __syncthreads();
-        float part = 0.f;
+        float part = 0.f, bsum = 0.f;
 #pragma unroll
         for (int k = 0; k < GMAXPP; ++k) {   // blur along the first dimension, ratio, temporal difference
             const int i = tid + k * GNT;
@@ -82,11 +84,27 @@ phase_extract_generic_kernel(const float* __restrict__ coeff, float* __restrict_
                     sd = fmaf(g_gauss[t], ok ? tmp_den[yy * C + x] : 0.f, sd);
                 }
                 const float blur = sn / sd;
+                bsum += blur;
                 if (p > 0) {
                     dcur[k] = blur - prev_blur[k];
                     part += dcur[k];
                 }
                 prev_blur[k] = blur;
+            }
+        }
+        if (dp) {   // training-side option (Aff-wild-exps/utils.py:410-412,417): the mean-centred denoised phase itself
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) bsum += __shfl_down(bsum, off, 64);
+            if (lane == 0) red2[wave] = bsum;
+            __syncthreads();
+            float s2 = 0.f;
+#pragma unroll
+            for (int w = 0; w < GNT / 64; ++w) s2 += red2[w];
+            const float bmean = s2 / (float)npix;
+#pragma unroll
+            for (int k = 0; k < GMAXPP; ++k) {
+                const int i = tid + k * GNT;
+                if (i < npix) dp[(size_t)p * npix + i] = prev_blur[k] - bmean;   // prev_blur holds this frame's value now
             }
         }
         if (p > 0) {   // spatial mean of this difference plane, then mean removal + clamp (:130-133)
@@ -111,7 +129,8 @@ phase_extract_generic_kernel(const float* __restrict__ coeff, float* __restrict_
 }  // namespace
 }  // namespace mm
 
-extern "C" int mm_phase_extract_generic(const float* coeff, int64_t planes, int P, int R, int C, float* out, void* stream) {
+extern "C" int mm_phase_extract_generic(const float* coeff, int64_t planes, int P, int R, int C, float* out, float* denoised,
+                                        void* stream) {
     if (planes < 0 || P < 2 || R <= 0 || C <= 0 || (planes > 0 && (!coeff || !out))) return MM_ERR_INVALID_ARG;
     if ((int64_t)R * C > (int64_t)mm::GNT * mm::GMAXPP || planes > 0x7fffffff) return MM_ERR_UNSUPPORTED;
     if (planes == 0) return MM_OK;
@@ -119,7 +138,7 @@ extern "C" int mm_phase_extract_generic(const float* coeff, int64_t planes, int 
     MM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(mm::phase_extract_generic_kernel),
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(mm::phase_extract_generic_kernel, dim3((unsigned)planes), dim3(mm::GNT), lds, (hipStream_t)stream, coeff, out,
-                       P, R, C);
+                       denoised, P, R, C);
     MM_LAUNCH_CHECK();
     return MM_OK;
 }

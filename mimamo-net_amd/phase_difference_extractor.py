@@ -125,7 +125,7 @@ class Phase_Difference_Extractor(object):
         c = coeff_batch.contiguous()
         out = torch.empty((B, nb, P - 1, W, H), dtype=torch.float32, device=c.device)
         if not (W == H and W in (48, 24) and nb == 2 and P == 13 and (self.height, self.nbands, self.scale_factor) == (4, 2, 2)):
-            rc = _lib.lib().mm_phase_extract_generic(_lib.ptr(c), B * nb, P, W, H, _lib.ptr(out), _lib.current_stream())
+            rc = _lib.lib().mm_phase_extract_generic(_lib.ptr(c), B * nb, P, W, H, _lib.ptr(out), None, _lib.current_stream())
             _lib.check(rc, "mm_phase_extract_generic")
             return out
         h = self._get(self._size if self._size is not None else 48)
@@ -188,3 +188,41 @@ def phase_diff_output(phase_batch, steerable_pyramid):
         n, n_ch, n_ph, w, h = d.size()
         outs.append(d.view(bs, num_frames, n_ch * n_ph, w, h))
     return tuple(outs)
+
+
+class Steerable_Pyramid_Phase(Phase_Difference_Extractor):
+    """Training-side twin of Phase_Difference_Extractor (Aff-wild-exps/utils.py:298-418, OMG-exps/utils.py): same
+    constructor plus `device`, same `build_pyramid`, and `extract_phase(coeff, return_phase, return_both)`.
+
+    The reference's own extract_phase cannot be run for a golden here (its blur passes a float64 kernel to F.conv2d on
+    float32 data, utils.py:246-256, which modern and period PyTorch reject on CPU), so this class is checked against
+    the oracle's restatement only -- parity unpinned for this training-side surface."""
+
+    def __init__(self, height=5, nbands=4, scale_factor=2, device=None, extract_level=1, visualize=False):
+        Phase_Difference_Extractor.__init__(self, height, nbands, scale_factor, extract_level, visualize)
+        self.device = device
+
+    def extract_phase(self, coeff_batch, return_phase=False, return_both=False):
+        """coeff [B, nbands, P, W, H, 2] -> phase differences [B, nbands, P-1, W, H] (default), the mean-centred
+        denoised phase [B, nbands, P, W, H] (return_phase) or their interleave (return_both)."""
+        self._check_input(coeff_batch, 6, "coeff_batch")
+        B, nb, P, W, H, two = coeff_batch.shape
+        assert two == 2
+        if not (return_phase or return_both):
+            return self.extract(coeff_batch)
+        c = coeff_batch.contiguous()
+        diff = torch.empty((B, nb, P - 1, W, H), dtype=torch.float32, device=c.device)
+        den = torch.empty((B, nb, P, W, H), dtype=torch.float32, device=c.device)
+        rc = _lib.lib().mm_phase_extract_generic(_lib.ptr(c), B * nb, P, W, H, _lib.ptr(diff), _lib.ptr(den), _lib.current_stream())
+        _lib.check(rc, "mm_phase_extract_generic")
+        if return_both:
+            # insert_tensors (utils.py:419-432) loops over t_a.size(dim) = P-1 positions of a 2(P-1)-long result: only its
+            # first half is ever written (even slots: diff[i//2], odd slots: denoised[1 + i//2]), the rest stays zero.
+            # Reproduced as is.
+            L = P - 1
+            both = torch.zeros((B, nb, 2 * L, W, H), dtype=torch.float32, device=c.device)
+            ne, no = (L + 1) // 2, L // 2
+            both[:, :, 0:L:2] = diff[:, :, :ne]
+            both[:, :, 1:L:2] = den[:, :, 1:1 + no]
+            return both
+        return den

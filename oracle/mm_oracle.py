@@ -256,6 +256,33 @@ def extract(coeff, dtype=np.float32):
     return np.clip(d, -lim, lim).astype(dtype)
 
 
+def extract_phase(coeff, return_phase=False, return_both=False, dtype=np.float32):
+    """Training-side Steerable_Pyramid_Phase.extract_phase (Aff-wild-exps/utils.py:367-418): extract() plus the options
+    to return the mean-centred denoised phase (:410-412,417) or insert_tensors(diff, denoised[1:]) (:413-416,419-432 --
+    whose loop runs over half of the result, the other half stays zero).  NOT pinned by a golden: the reference's own
+    blur (utils.py:246-256) feeds a float64 kernel to F.conv2d on float32 data and does not run."""
+    coeff = np.asarray(coeff).astype(dtype)
+    b, nb, p, w, h, _ = coeff.shape
+    re = torch.from_numpy(np.ascontiguousarray(coeff[..., 0]))
+    im = torch.from_numpy(np.ascontiguousarray(coeff[..., 1]))
+    phase = torch.atan2(im, re).numpy().reshape(b * nb, p, w, h)
+    mag = (torch.sqrt(im * im + re * re).numpy().reshape(b * nb, p, w, h) + np.dtype(dtype).type(1e-10)).astype(dtype)
+    den = amplitude_blur(mag, unwrap(phase, axis=1), gaussian_kernel(2, 11)).reshape(b, nb, p, w, h)
+    d = diff(den, axis=2)
+    den_c = den - den.mean(-1).mean(-1)[..., None, None]
+    d = d - d.mean(-1).mean(-1)[..., None, None]
+    lim = np.dtype(dtype).type(5 * PI)
+    d = np.clip(d, -lim, lim).astype(dtype)
+    if return_both:
+        t_a, t_b = d, den_c[:, :, 1:]
+        length = t_a.shape[2]
+        res = np.zeros((b, nb, 2 * length, w, h), dtype=dtype)
+        for i in range(length):
+            res[:, :, i] = (t_a if i % 2 == 0 else t_b)[:, :, i // 2]
+        return res
+    return den_c.astype(dtype) if return_phase else d
+
+
 def phase_diff_output(phase_batch, height=4, nbands=2, extract_level=(1, 2), dtype=np.float32):
     """Tester.phase_diff_output (tester.py:122-139): [bs,T,P,W,H] -> (phase_0, phase_1)."""
     bs, t, p, w, h = phase_batch.shape

@@ -297,7 +297,7 @@ def test_generic_extract_equals_fused_kernel(pde, oracle, dev):
         fused = pde.extract(c)
         B, nb, P, W, H, _ = c.shape
         gen = torch.empty_like(fused)
-        rc = _lib.lib().mm_phase_extract_generic(_lib.ptr(c.contiguous()), B * nb, P, W, H, _lib.ptr(gen), _lib.current_stream())
+        rc = _lib.lib().mm_phase_extract_generic(_lib.ptr(c.contiguous()), B * nb, P, W, H, _lib.ptr(gen), None, _lib.current_stream())
         assert rc == 0
         assert (fused - gen).abs().max() < 2e-6
     # a window length the fused kernel does not implement goes to the generic kernel through the same method
@@ -305,3 +305,28 @@ def test_generic_extract_equals_fused_kernel(pde, oracle, dev):
     want = oracle.extract(c1[:, :, :7].cpu().numpy())
     mx, p9999, flips = _phase_err(d7.cpu().numpy(), want)
     assert tuple(d7.shape) == (1, 2, 6, 48, 48) and mx < PHASE_ATOL and p9999 < PHASE_P9999 and flips <= 2
+
+
+def test_training_side_steerable_pyramid_phase(pkg, oracle, dev):
+    """Steerable_Pyramid_Phase (Aff-wild-exps/utils.py:298-418): extract_phase default / return_phase / return_both
+    (incl. insert_tensors' half-filled result) against the oracle's restatement; the default equals extract()."""
+    from mimamo_net_amd.phase_difference_extractor import Steerable_Pyramid_Phase
+    sp = Steerable_Pyramid_Phase(height=4, nbands=2, scale_factor=2, device=dev, extract_level=[1, 2], visualize=False)
+    x = torch.from_numpy(synthetic.textured_gray(13, 48, seed=93))[None].to(dev)
+    coeffs = sp.build_pyramid(x)
+    for c in coeffs:
+        cn = c.cpu().numpy()
+        d = sp.extract_phase(c)
+        assert torch.equal(d, sp.extract(c))
+        den = sp.extract_phase(c, return_phase=True)
+        want = oracle.extract_phase(cn, return_phase=True)
+        mx, p9999, flips = _phase_err(den.cpu().numpy(), want)
+        assert tuple(den.shape) == want.shape and mx < PHASE_ATOL and p9999 < PHASE_P9999 and flips <= 2, (mx, p9999, flips)
+        assert den.mean(dim=(-1, -2)).abs().max() < 1e-4                       # mean-centred
+        both = sp.extract_phase(c, return_both=True)
+        wb = oracle.extract_phase(cn, return_both=True)
+        L = c.shape[2] - 1
+        assert tuple(both.shape) == wb.shape == (1, 2, 2 * L, c.shape[3], c.shape[4])
+        assert both[:, :, L:].abs().max() == 0 and np.abs(wb[:, :, L:]).max() == 0   # the reference's loop stops half way
+        mx, p9999, flips = _phase_err(both.cpu().numpy(), wb)
+        assert mx < PHASE_ATOL and p9999 < PHASE_P9999 and flips <= 2
