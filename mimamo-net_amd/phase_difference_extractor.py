@@ -194,9 +194,10 @@ class Steerable_Pyramid_Phase(Phase_Difference_Extractor):
     """Training-side twin of Phase_Difference_Extractor (Aff-wild-exps/utils.py:298-418, OMG-exps/utils.py): same
     constructor plus `device`, same `build_pyramid`, and `extract_phase(coeff, return_phase, return_both)`.
 
-    The reference's own extract_phase cannot be run for a golden here (its blur passes a float64 kernel to F.conv2d on
-    float32 data, utils.py:246-256, which modern and period PyTorch reject on CPU), so this class is checked against
-    the oracle's restatement only -- parity unpinned for this training-side surface."""
+    The reference's own extract_phase cannot be run for a golden in the build container: its blur converts the Gaussian
+    kernel to float32 only `if phase.is_cuda` (utils.py:254), so on a CPU-only host F.conv2d gets a float64 kernel and
+    raises.  On CUDA it is the same arithmetic as api/utils/phase_utils.py:78-90 (float32 kernel), which IS pinned; this
+    class is therefore checked against the oracle's restatement -- no golden of its own."""
 
     def __init__(self, height=5, nbands=4, scale_factor=2, device=None, extract_level=1, visualize=False):
         Phase_Difference_Extractor.__init__(self, height, nbands, scale_factor, extract_level, visualize)
