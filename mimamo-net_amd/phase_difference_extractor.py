@@ -196,8 +196,9 @@ class Steerable_Pyramid_Phase(Phase_Difference_Extractor):
 
     The reference's own extract_phase cannot be run for a golden in the build container: its blur converts the Gaussian
     kernel to float32 only `if phase.is_cuda` (utils.py:254), so on a CPU-only host F.conv2d gets a float64 kernel and
-    raises.  On CUDA it is the same arithmetic as api/utils/phase_utils.py:78-90 (float32 kernel), which IS pinned; this
-    class is therefore checked against the oracle's restatement -- no golden of its own."""
+    raises.  On CUDA it is the same arithmetic as api/utils/phase_utils.py:78-90 (float32 kernel), which IS pinned; the
+    golden for this class (tests/golden/train_phase.npz) comes from running the real reference's extract_phase on the
+    float64 cast of its own fp32 coefficients, where the CPU path does work."""
 
     def __init__(self, height=5, nbands=4, scale_factor=2, device=None, extract_level=1, visualize=False):
         Phase_Difference_Extractor.__init__(self, height, nbands, scale_factor, extract_level, visualize)

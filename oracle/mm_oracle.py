@@ -259,9 +259,9 @@ def extract(coeff, dtype=np.float32):
 def extract_phase(coeff, return_phase=False, return_both=False, dtype=np.float32):
     """Training-side Steerable_Pyramid_Phase.extract_phase (Aff-wild-exps/utils.py:367-418): extract() plus the options
     to return the mean-centred denoised phase (:410-412,417) or insert_tensors(diff, denoised[1:]) (:413-416,419-432 --
-    whose loop runs over half of the result, the other half stays zero).  No golden of its own: the reference's training-
-    side blur casts the kernel to float32 only on CUDA (utils.py:254) and raises on this CPU-only host; on CUDA it is the
-    arithmetic of api/utils/phase_utils.py:78-90, which extract() restates and G3/G9 pin."""
+    whose loop runs over half of the result, the other half stays zero).  Pinned by G10 (tests/golden/train_phase.npz): the
+    real class run on the float64 cast of its fp32 coefficients (its blur casts the kernel to float32 only on CUDA,
+    utils.py:254, so float32 data raises on this CPU-only host while float64 data runs)."""
     coeff = np.asarray(coeff).astype(dtype)
     b, nb, p, w, h, _ = coeff.shape
     re = torch.from_numpy(np.ascontiguousarray(coeff[..., 0]))

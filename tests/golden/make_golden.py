@@ -24,6 +24,9 @@ arguments and the reference's outputs are saved.
   G9 phase_generic.npz  Phase_Difference_Extractor with OTHER constructor arguments than api/tester.py's: (height 3, 4 bands,
                     level 1, 5 textured 32x32 frames, symmetry) and (height 3, 2 bands, level [1], 3 frames, symmetry=False),
                     and the class defaults (height 5, 4 bands, level 1) on 64x64 frames: build_pyramid -> extract outputs
+  G10 train_phase.npz  training-side Steerable_Pyramid_Phase (Aff-wild-exps/utils.py:298-418): build_pyramid in fp32, then
+                    extract_phase(default / return_phase / return_both) on the float64 cast of those coefficients (the
+                    class's blur only casts its kernel to float32 on CUDA, so on this CPU-only host it runs in float64)
   G7 sampler.npz    Snippet_Sampler.seq_ranges for N in {10,64,100,128,309} and the 13-frame window
                     ids decoded from constant-valued BMPs, + one textured BMP pass pinning
                     convert('L') + Lanczos 112->48 + /255
@@ -284,6 +287,34 @@ def g9_phase_generic(ref):
     np.savez_compressed(os.path.join(HERE, "phase_generic.npz"), **out)
 
 
+def g10_train_phase(ref):
+    import types
+    path = "/root/reference/Aff-wild-exps/utils.py"
+    src = open(path).read().replace("async=True", "non_blocking=True")     # same py<3.7 keyword as shim 4
+    mod = types.ModuleType("affwild_utils")
+    mod.__file__ = path
+    exec(compile(src, path, "exec"), mod.__dict__)
+    sp = mod.Steerable_Pyramid_Phase(height=4, nbands=2, scale_factor=2, device=torch.device("cpu"), extract_level=[1, 2],
+                                     visualize=False)
+    torch.set_default_dtype(torch.float32)
+    x = torch.from_numpy(synthetic.textured_gray(6, 48, seed=41))[None]           # [1,6,48,48]
+    c1, c2 = sp.build_pyramid(x)
+    out = {"c1": c1.numpy(), "c2": c2.numpy()}
+    for tag, c in (("l1", c1), ("l2", c2)):
+        cd = c.double()
+        out[tag + "_diff"] = sp.extract_phase(cd).numpy().astype(np.float32)
+        out[tag + "_phase"] = sp.extract_phase(cd, return_phase=True).numpy().astype(np.float32)
+        sp_cuda = torch.Tensor.cuda
+        torch.Tensor.cuda = lambda self, *a, **k: self                          # return_both ends with result.cuda() (:416)
+        try:
+            out[tag + "_both"] = sp.extract_phase(cd, return_both=True).numpy().astype(np.float32)
+        finally:
+            torch.Tensor.cuda = sp_cuda
+    torch.set_default_dtype(torch.float32)
+    print("G10", {k: v.shape for k, v in out.items()})
+    np.savez_compressed(os.path.join(HERE, "train_phase.npz"), **out)
+
+
 SCF_FULL_CASES = [
     # tag, size, height, nbands, n_images, seed, stored dtype
     ("a", 96, 4, 2, 1, 8, np.float32),
@@ -314,6 +345,9 @@ if __name__ == "__main__":
         if sys.argv[1:]:
             sys.exit(0)
     ref = ref_shim.load()
+    if sys.argv[1:] == ["g10"]:
+        g10_train_phase(ref)
+        sys.exit(0)
     if sys.argv[1:] == ["g9"]:
         g9_phase_generic(ref)
         sys.exit(0)
@@ -328,4 +362,5 @@ if __name__ == "__main__":
     g7_sampler(ref)
     g8_scfpyr_full(ref)
     g9_phase_generic(ref)
+    g10_train_phase(ref)
     os.system("ls -la %s" % HERE)

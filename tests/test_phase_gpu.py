@@ -330,3 +330,17 @@ def test_training_side_steerable_pyramid_phase(pkg, oracle, dev):
         assert both[:, :, L:].abs().max() == 0 and np.abs(wb[:, :, L:]).max() == 0   # the reference's loop stops half way
         mx, p9999, flips = _phase_err(both.cpu().numpy(), wb)
         assert mx < PHASE_ATOL and p9999 < PHASE_P9999 and flips <= 2
+
+
+def test_training_side_golden(pkg, golden, dev):
+    """Steerable_Pyramid_Phase on the real reference's coefficients vs the real reference's (float64) outputs."""
+    from mimamo_net_amd.phase_difference_extractor import Steerable_Pyramid_Phase
+    g = golden("train_phase")
+    sp = Steerable_Pyramid_Phase(height=4, nbands=2, scale_factor=2, device=dev, extract_level=[1, 2])
+    for tag, key in (("l1", "c1"), ("l2", "c2")):
+        c = torch.from_numpy(g[key]).to(dev)
+        for name, kw in (("diff", {}), ("phase", {"return_phase": True}), ("both", {"return_both": True})):
+            got = sp.extract_phase(c, **kw).cpu().numpy()
+            want = g["%s_%s" % (tag, name)]
+            mx, p9999, flips = _phase_err(got, want)
+            assert got.shape == want.shape and mx < PHASE_ATOL and p9999 < PHASE_P9999 and flips <= 2, (tag, name, mx, p9999, flips)
