@@ -190,6 +190,20 @@ def phase_diff_output(phase_batch, steerable_pyramid):
     return tuple(outs)
 
 
+def phase_2_output(phase_batch, steerable_pyramid, return_phase=False):
+    """The training data loaders' per-item call (Aff-wild-exps/dataloader.py:61-75, OMG-exps/dataloader.py:59-73):
+    phase_batch [num_frames, num_phases, W, H] -> (phase_0 [num_frames, nbands*n_ph, W, H], phase_1 [.., W/2, H/2])."""
+    sp = steerable_pyramid
+    coeff_batch = sp.build_pyramid(phase_batch)
+    assert isinstance(coeff_batch, list)
+    outs = []
+    for c in coeff_batch[:2]:
+        d = sp.extract_phase(c, return_phase=return_phase)
+        n, n_ch, n_ph, w, h = d.size()
+        outs.append(d.view(n, -1, w, h))
+    return tuple(outs)
+
+
 class Steerable_Pyramid_Phase(Phase_Difference_Extractor):
     """Training-side twin of Phase_Difference_Extractor (Aff-wild-exps/utils.py:298-418, OMG-exps/utils.py): same
     constructor plus `device`, same `build_pyramid`, and `extract_phase(coeff, return_phase, return_both)`.

@@ -332,6 +332,19 @@ def test_training_side_steerable_pyramid_phase(pkg, oracle, dev):
         assert mx < PHASE_ATOL and p9999 < PHASE_P9999 and flips <= 2
 
 
+def test_training_loader_call(pkg, pde, dev):
+    """phase_2_output (Aff-wild-exps/dataloader.py:61-75): same tensors as the inference-side phase_diff_output."""
+    from mimamo_net_amd.phase_difference_extractor import Steerable_Pyramid_Phase, phase_2_output, phase_diff_output
+    sp = Steerable_Pyramid_Phase(height=4, nbands=2, scale_factor=2, device=dev, extract_level=[1, 2])
+    x = torch.from_numpy(synthetic.textured_gray(5 * 13, 48, seed=95)).view(5, 13, 48, 48).to(dev)
+    a0, a1 = phase_2_output(x, sp)
+    b0, b1 = phase_diff_output(x[None], pde)
+    assert tuple(a0.shape) == (5, 24, 48, 48) and tuple(a1.shape) == (5, 24, 24, 24)
+    assert torch.equal(a0, b0[0]) and torch.equal(a1, b1[0])
+    p0, p1 = phase_2_output(x, sp, return_phase=True)
+    assert tuple(p0.shape) == (5, 26, 48, 48) and tuple(p1.shape) == (5, 26, 24, 24)
+
+
 def test_training_side_golden(pkg, golden, dev):
     """Steerable_Pyramid_Phase on the real reference's coefficients vs the real reference's (float64) outputs."""
     from mimamo_net_amd.phase_difference_extractor import Steerable_Pyramid_Phase
