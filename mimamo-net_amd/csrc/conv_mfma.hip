@@ -5,7 +5,8 @@
 //     Resnet50_Extractor.get_vec (api/resnet50_extractor.py:74-83),
 //   * PhaseNet's six 3x3 convs and every nn.Linear of Two_Stream_RNN (api/mimamo_net.py:14-26,
 //     41-95,115-122), the GRU input/recurrent products (api/mimamo_net.py:119) -- a Linear is a
-//     1x1 conv on a 1x1 image.
+//     1x1 conv on a 1x1 image,
+//   * the batched Winograd-domain GEMMs of the stride-1 3x3 ResNet layers (36 problems per launch, winograd.hip).
 // fp32 in / fp32 accumulate: the MFMA is bit-for-bit an fmaf chain, so results differ from the
 // reference's fp32 convs only by summation order (the 1e-4 output tolerance of north_star rules
 // out bf16/fp16 operands).
@@ -23,7 +24,8 @@
 // b128 read feeds four MFMAs.  Zero padding of every kind comes from the buffer descriptors' range check.
 // Epilogue (fused): + bias (BN folded on the host) [+ residual] [ReLU] [* post_scale + post_shift]
 // (BN placed after ReLU, mimamo_net.py:54-62,115-117); the accumulator tile is transposed through LDS so
-// bias/residual/output move as 16-byte accesses, 256 bytes per row.
+// bias/residual/output move as 16-byte accesses, 256 bytes per row (wave-private staging, no workgroup barrier;
+// outputs are written with the non-temporal hint: the next layer reads them from HBM, not from L2).
 #include "mm_common.h"
 #include <cstdio>
 #include "conv.h"
