@@ -90,8 +90,16 @@ class HotPath(object):
                 plans.append(self.plan(video_lengths[a:b]))
                 frs.append((off, off + n))
                 off += n
-            self._lane_cache = cache = (key, plans, frs, [torch.cuda.Stream(device=self.device) for _ in range(lanes)])
-        _, plans, frs, streams = cache
+            self._lane_cache = cache = (key, plans, frs)
+        _, plans, frs = cache
+        # one persistent pool of side streams: per-stream workspaces (Resnet50_Extractor) are keyed by stream, so new
+        # streams for every new (lengths, lanes) combination would strand tens of GB of workspace each
+        pool = getattr(self, "_lane_streams", None)
+        if pool is None:
+            pool = self._lane_streams = []
+        while len(pool) < lanes:
+            pool.append(torch.cuda.Stream(device=self.device))
+        streams = pool[:lanes]
         cur = torch.cuda.current_stream()
         outs = []
         for plan, (f0, f1), st in zip(plans, frs, streams):

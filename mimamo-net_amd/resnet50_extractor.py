@@ -63,10 +63,13 @@ class Resnet50_Extractor(object):
     def _workspace(self, bs):
         need = _lib.lib().mm_resnet50_workspace_bytes(self._handle, bs)
         key = torch.cuda.current_stream().cuda_stream
-        ws = self._ws.get(key)
+        ws = self._ws.pop(key, None)          # re-inserted below: the dict is kept in least-recently-used order
         if ws is None or ws.numel() * 4 < need:
-            self._ws[key] = None
-            ws = self._ws[key] = torch.empty(((need + 3) // 4,), dtype=torch.float32, device=self.device)
+            ws = None
+            while len(self._ws) >= 8:         # bound what short-lived streams can strand (17 MB per frame each)
+                self._ws.pop(next(iter(self._ws)))
+            ws = torch.empty(((need + 3) // 4,), dtype=torch.float32, device=self.device)
+        self._ws[key] = ws
         return ws, need
 
     def get_vec(self, image, channels_last4=False):
