@@ -118,6 +118,33 @@ def test_bench_sized_step_is_deterministic(tester):
     assert torch.equal(a, b) and torch.equal(a, c)
 
 
+def test_awkward_video_lengths_alone_and_in_mixed_batches(tester):
+    """Videos of 1, 2, 13, 63, 64, 65, 129, 309 frames (short-video rule, tail-snippet overlap, single-frame windows):
+    finite, right shapes, and the same values whether a video is processed alone or inside a mixed batch / on lanes."""
+    hot, dev = tester.hot, tester.device
+    lengths = [1, 2, 13, 63, 64, 65, 129, 309]
+    g = torch.Generator(device="cpu").manual_seed(3)
+    clips = {n: (torch.rand(n, 48, 48, generator=g).to(dev), (torch.rand(n, 3, 224, 224, generator=g) * 200 - 100).to(dev))
+             for n in lengths}
+    alone = {}
+    with torch.no_grad():
+        for n in lengths:
+            plan = hot.plan([n])
+            res = hot.assemble(hot.forward(*clips[n], plan), plan)[0]
+            assert res.shape == (n, 2) and np.isfinite(res).all(), n
+            alone[n] = res
+        rng = np.random.RandomState(0)
+        for it in range(8):
+            pick = [lengths[i] for i in rng.randint(0, len(lengths), size=int(rng.randint(2, 5)))]
+            gray = torch.cat([clips[n][0] for n in pick])
+            rgb = torch.cat([clips[n][1] for n in pick])
+            plan = hot.plan(pick)
+            out = hot.forward(gray, rgb, plan) if it % 2 else hot.forward_lanes((gray, rgb), pick, 2)
+            res = hot.assemble(out, plan)
+            for i, n in enumerate(pick):
+                assert res[i].shape == (n, 2) and np.abs(res[i] - alone[n]).max() < 1e-5, (pick, i, n)
+
+
 def test_hot_path_is_hip_graph_capturable(tester):
     """The C ABI only enqueues on the given stream (no hidden synchronisation, allocation or host copy): one pass of the
     whole path can be captured in a HIP graph and replayed on new input values with bit-identical results."""
