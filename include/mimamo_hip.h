@@ -162,7 +162,7 @@ typedef struct mm_head mm_head_t;
  *     korder 0: k = (r*kw + s)*Cin + c;  korder 1 (Cin % 16 == 0): k = ((c/16*kh + r)*kw + s)*16 + c%16
  *     (slice-major: the taps of a 16-channel slice are adjacent, which keeps the kh*kw-fold input re-use in L2)
  * out [B,Ho,Wo,out_cstride] channels [out_coff, out_coff+Cout) are written; residual [B,Ho,Wo,res_cstride].
- * bias/residual/post_scale/post_shift may be NULL.  tile: 0 auto, 1 = 128x128, 2 = 128x64, 3 = 64x64, 4 = 256x64.
+ * bias/residual/post_scale/post_shift may be NULL.  tile: 0 auto, 1 = 128x128, 2 = 128x64, 3 = 64x64, 4 = 256x64, 5 = 128x256 (1x1 kernels only).
  * This is what torch.nn.functional.conv2d / linear + BatchNorm(eval) + ReLU lower to on this path
  * (api/mimamo_net.py:14-26,68-78; the third-party ResNet50's conv/bn/relu triples). */
 int mm_conv2d_nhwc(const float* in, const float* w, const float* bias, const float* residual,

@@ -50,6 +50,8 @@ CASES = [
     (1, 1, 1, 256, 8, 1, 1, 0, 0, 0),        # a single output row (M = 1)
     (2, 6, 6, 16, 32, 3, 1, 1, 1, 0),        # one 16-channel slice
     (1, 9, 9, 32, 48, 5, 1, 2, 0, 1),        # 5x5 taps, pad 2
+    (3, 14, 14, 64, 256, 1, 1, 0, 1, 5),     # 128x256 tile, eight waves: M = 588 (ragged), one n-tile
+    (2, 10, 10, 72, 320, 1, 2, 0, 0, 5),     # 128x256 tile: strided 1x1, K = 72 (tail), N = 320 (ragged second n-tile)
 ]
 
 
@@ -96,6 +98,7 @@ STRESS = [
     (400000, 1, 64, 64, 1, 2, 0, 8),
     (400000, 1, 64, 128, 1, 1, 0, 8),
     (200000, 1, 64, 64, 1, 4, 0, 8),
+    (200000, 1, 64, 256, 1, 5, 0, 8),
     (256, 28, 64, 64, 3, 3, 1, 8),
 ]
 

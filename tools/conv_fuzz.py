@@ -38,7 +38,7 @@ for it in range(N):
     if (H + 2 * pad - k) < 0 or (W + 2 * pad - k) < 0:
         continue
     korder = int(rng.randint(0, 2)) if (Ci % 16 == 0 and k > 1) else 0
-    tile = int(rng.choice([0, 1, 2, 3, 4]))
+    tile = int(rng.choice([0, 1, 2, 3, 4, 5] if (k == 1 and pad == 0) else [0, 1, 2, 3, 4]))
     relu = int(rng.randint(0, 2)); use_res = int(rng.randint(0, 2)); use_post = int(rng.randint(0, 2)); use_bias = int(rng.randint(0, 2))
     wide = Co % 4 == 0
     in_off = 4 * int(rng.randint(0, 3)); in_cs = Ci + in_off + 4 * int(rng.randint(0, 3))
