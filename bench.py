@@ -48,32 +48,24 @@ def make_inputs(n_clips, rank, device):
     return gray, rgb
 
 
-def cpu_baseline(n_clips, head_sd, resnet_sd):
-    """Oracle (reference-semantics PyTorch-CPU restatement incl. the 13x redundant pyramid) on `n_clips`
-    64-frame clips.  PyTorch's default of one thread per logical core collapses on big hosts (256 threads:
-    0.4 frames/s on the bench box), so the thread count is calibrated first and reported as `cores`."""
+def _cpu_worker(first_clip, n_clips, threads, out_path):
+    """One host process of the CPU baseline: the oracle (reference semantics incl. the 13x redundant pyramid) on
+    `n_clips` 64-frame clips with `threads` PyTorch threads.  Prints one JSON line with its timings."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import mm_oracle
-    from mimamo_net_amd import synthetic, sampler
-    ncpu = os.cpu_count() or 1
-    clip = synthetic.make_clip_u8(0, FRAMES_PER_CLIP)
-    gray, rgb = synthetic.preprocess_host(clip)
-    best, best_t = 1, float("inf")
-    for nt in sorted({min(ncpu, t) for t in (8, 16, 32, 64)}):
-        torch.set_num_threads(nt)
-        mm_oracle.resnet50_pool5(resnet_sd, rgb[:4])
-        t0 = time.time()
-        mm_oracle.resnet50_pool5(resnet_sd, rgb[:16])
-        dt = time.time() - t0
-        if dt < best_t:
-            best, best_t = nt, dt
-    torch.set_num_threads(best)
+    import mimamo_net_amd  # noqa: F401
+    from mimamo_net_amd import synthetic, sampler, weights
+    torch.set_num_threads(threads)
+    head_sd = weights.make_two_stream_state_dict(seed=0)
+    resnet_sd = weights.make_resnet50_state_dict(seed=0)
     ids = sampler.window_ids(0, FRAMES_PER_CLIP, FRAMES_PER_CLIP)
+    gray, rgb = synthetic.preprocess_host(synthetic.make_clip_u8(first_clip, FRAMES_PER_CLIP))
+    mm_oracle.resnet50_pool5(resnet_sd, rgb[:4])                        # warm-up (thread pool, oneDNN primitives)
     tp = tr = th = 0.0
-    out0 = None
+    t_start = time.time()
     for c in range(n_clips):
         if c:
-            gray, rgb = synthetic.preprocess_host(synthetic.make_clip_u8(c, FRAMES_PER_CLIP))
+            gray, rgb = synthetic.preprocess_host(synthetic.make_clip_u8(first_clip + c, FRAMES_PER_CLIP))
         t0 = time.time()
         p0, p1 = mm_oracle.phase_diff_output(gray[ids][None])           # tester.py:122-139 (windowed, 13x redundant)
         t1 = time.time()
@@ -82,16 +74,59 @@ def cpu_baseline(n_clips, head_sd, resnet_sd):
         out = mm_oracle.two_stream_forward(head_sd, p0, p1, feats[None])  # mimamo_net.py:129-143
         t3 = time.time()
         tp, tr, th = tp + t1 - t0, tr + t2 - t1, th + t3 - t2
-        if c == 0:
-            out0 = out
-    total = tp + tr + th
-    n = n_clips * FRAMES_PER_CLIP
-    return {"value": n / total, "unit": "frames/s", "cores": best, "kind": "port",
-            "sample": "%d clips x 64 frames, oracle/mm_oracle.py on PyTorch-CPU fp32, %d of %d host threads (calibrated); "
-                      "phase %.2fs, resnet50 %.2fs, head %.2fs" % (n_clips, best, ncpu, tp, tr, th)}, out0
+        if c == 0 and out_path:
+            np.save(out_path, out)
+    print(json.dumps({"t_start": t_start, "t_end": time.time(), "phase": tp, "resnet": tr, "head": th,
+                      "frames": n_clips * FRAMES_PER_CLIP}))
+
+
+def cpu_baseline(n_clips, head_sd, resnet_sd):
+    """The oracle on the host's cores: PyTorch's intra-op pool stops scaling at ~16 threads on this path (one thread per
+    logical core collapses to 0.4 frames/s on the 256-thread bench host), so the host is filled with several
+    processes of a calibrated thread count each, every process working on its own clips -- the same sharding the GPU
+    path uses.  value = all frames / wall time from the first process's start of compute to the last one's end."""
+    import subprocess
+    import tempfile
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import mm_oracle
+    from mimamo_net_amd import synthetic
+    ncpu = os.cpu_count() or 1
+    gray, rgb = synthetic.preprocess_host(synthetic.make_clip_u8(0, FRAMES_PER_CLIP))
+    best, best_t = 1, float("inf")
+    for nt in sorted({min(ncpu, t) for t in (8, 16, 32)}):
+        torch.set_num_threads(nt)
+        mm_oracle.resnet50_pool5(resnet_sd, rgb[:4])
+        t0 = time.time()
+        mm_oracle.resnet50_pool5(resnet_sd, rgb[:16])
+        dt = (time.time() - t0) * nt          # core-seconds: prefer the thread count that uses cores best
+        if dt < best_t:
+            best, best_t = nt, dt
+    procs = max(1, min(n_clips, (ncpu // 2) // best))      # physical cores (SMT pairs) / threads per process
+    per = max(1, n_clips // procs)
+    tmp = tempfile.mkdtemp(prefix="mm_cpu_")
+    out0 = os.path.join(tmp, "clip0.npy")
+    env = dict(os.environ, OMP_NUM_THREADS=str(best), MKL_NUM_THREADS=str(best))
+    ps = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-worker", str(i * per), str(per), str(best),
+                            out0 if i == 0 else ""], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, env=env,
+                           universal_newlines=True) for i in range(procs)]
+    recs = []
+    for pr in ps:
+        so, _ = pr.communicate()
+        recs.append(json.loads([l for l in so.splitlines() if l.startswith("{")][-1]))
+    wall = max(r["t_end"] for r in recs) - min(r["t_start"] for r in recs)
+    frames = sum(r["frames"] for r in recs)
+    cpu_out = np.load(out0)
+    return {"value": frames / wall, "unit": "frames/s", "cores": procs * best, "kind": "port",
+            "sample": "%d clips x 64 frames in %d processes x %d threads (%d logical CPUs), oracle/mm_oracle.py on PyTorch-CPU "
+                      "fp32, %.1f s wall; per process: phase %.1f s, resnet50 %.1f s, head %.1f s"
+                      % (procs * per, procs, best, ncpu, wall, np.mean([r["phase"] for r in recs]),
+                         np.mean([r["resnet"] for r in recs]), np.mean([r["head"] for r in recs]))}, cpu_out
 
 
 def main():
+    if len(sys.argv) >= 6 and sys.argv[1] == "--cpu-worker":
+        _cpu_worker(int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), sys.argv[5])
+        return
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
@@ -110,7 +145,7 @@ def main():
     ap.add_argument("--from-u8", action="store_true",
                     help="start every step from the raw boundary (uint8 112x112x3 aligned faces in HBM): adds the "
                          "PIL-exact on-GPU preprocessing to the timed region")
-    ap.add_argument("--cpu-clips", type=int, default=8, help="64-frame clips timed on the host for cpu_baseline")
+    ap.add_argument("--cpu-clips", type=int, default=16, help="64-frame clips timed on the host for cpu_baseline (all processes together)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
