@@ -2,22 +2,27 @@
 """bench.py -- end-to-end throughput of the MIMAMO-Net per-video inference hot path on MI355X.
 
 Metric (BASELINE.json): face-frames/sec end-to-end (phase-diff + ResNet50 + 2-stream GRU), 64-frame clips.
-Workload at N=1 (BASELINE configs[3]): a batch of independent 64-frame clips, full two-stream path
-(steerable pyramid + phase difference, ResNet50 pool5, PhaseNet/MLP/GRU head), fp32, random-init weights of
-the reference architecture, synthetic 112x112 aligned-face clips preprocessed to the tensors the reference's
-hot path consumes (gray 48x48 in [0,1]; RGB 224x224 = 255x-mean), resident in HBM before the timed region.
-One step = one pass of the hot path over `--clips` clips (default 32 -> 2048 frames) per GPU.
+Workload at N=1 (BASELINE configs[3]): a batch of independent 64-frame clips, full two-stream path -- PIL-exact
+preprocessing of the uint8 112x112x3 aligned faces (the raw boundary, resident in HBM before the timed region),
+steerable pyramid + phase difference, ResNet50 pool5, PhaseNet/MLP/GRU head -- fp32, random-init weights of the
+reference architecture.  One step = one pass of the hot path over `--clips` clips (default 32 -> 2048 frames) per GPU.
 
-N>1: one process per GPU (torch.distributed, backend nccl = RCCL), clips sharded across ranks (weak scaling,
-`--clips` per rank), no data-path collective; per-clip results are all-gathered (8 B/frame) inside the timed
-region; the time is the max over ranks.
+N>1 (BASELINE configs[4]): one process per GPU (torch.distributed, backend nccl = RCCL over xGMI).  `--gpus N`
+without a torchrun environment spawns the N ranks itself; under torchrun (WORLD_SIZE set) it must equal WORLD_SIZE.
+Rank 0 builds the work queue (`--total-clips` clip ids + lengths, default 10 000 at N>1), broadcasts it (RCCL),
+every rank takes its shard (`dist.shard`: clips c mod N == rank) and walks it `--clips` clips per step; per-step
+results ([frames,2], 8 B/frame) are all-gathered asynchronously.  No collective on the data path; weak scaling
+(per-GPU work per step is fixed); the time is the max over ranks.  `--whole-job` walks the entire queue once.
 
 Prints ONE JSON line (rank 0) with `roofline` (conv/GEMM engine on the fp32 matrix cores, timed live with
-hipEvents on the launch stream by the library's measurement hook) and `cpu_baseline` (the oracle's
-PyTorch-CPU restatement of the same path on a bounded sample, rank 0 / N=1 only).
+hipEvents on the launch stream by the library's measurement hook), `cpu_baseline` (the oracle's PyTorch-CPU
+restatement of the same path on a bounded sample, rank 0 / N=1 only) and `extra` (N=1: the same step in direct
+form without Winograd, and a step of multi-snippet 309-frame videos -- the reference's run_example shape: 5 snippets,
+GRU seq_len 5).
 """
 import argparse
 import ctypes
+import hashlib
 import json
 import os
 import sys
@@ -32,25 +37,40 @@ import torch  # noqa: E402
 PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CU x 4 SIMD x 64 FLOP/clk x 2.4 GHz
 PEAK_HBM_GBS = 8000.0
 FRAMES_PER_CLIP = 64
+EXAMPLE_VIDEO_FRAMES = 309      # api/readme.md:100 (utterance_1.mp4): 5 snippets of 64 (snippet_sampler.py:112-126)
 
 
-def make_inputs(n_clips, rank, device):
-    """Synthetic clips -> the hot path's input tensors on the device (data prep is outside the timed region)."""
-    from mimamo_net_amd import synthetic
-    grays, rgbs = [], []
-    for c in range(n_clips):
-        clip = synthetic.make_clip_u8(rank * n_clips + c, FRAMES_PER_CLIP)
-        g, r = synthetic.preprocess_host(clip)
-        grays.append(g)
-        rgbs.append(r)
-    gray = torch.from_numpy(np.concatenate(grays)).to(device)
-    rgb = torch.from_numpy(np.concatenate(rgbs)).to(device)
-    return gray, rgb
+def kernel_source_hash():
+    """sha256 over the HIP/C++ sources + headers: PMC traffic summaries under profiles/ record the hash of the kernels
+    they were measured on, and are only quoted when it still matches (they cannot be re-measured live: PMC counters need
+    rocprofv3)."""
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "mimamo-net_amd", "csrc")
+    for name in sorted(os.listdir(d)):
+        if name.endswith((".hip", ".cpp", ".h")):
+            with open(os.path.join(d, name), "rb") as f:
+                h.update(name.encode() + b"\0" + f.read())
+    return h.hexdigest()[:16]
 
 
-def _cpu_worker(first_clip, n_clips, threads, out_path):
-    """One host process of the CPU baseline: the oracle (reference semantics incl. the 13x redundant pyramid) on
-    `n_clips` 64-frame clips with `threads` PyTorch threads.  Prints one JSON line with its timings."""
+def cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+# ---------------------------------------------------------------------------------------------------------
+# CPU baseline (oracle = test infrastructure; used here only as the thing timed beside the HIP path)
+# ---------------------------------------------------------------------------------------------------------
+def _cpu_worker(first_clip, n_clips, threads, out_path, dedup):
+    """One host process of the CPU baseline: the oracle on `n_clips` 64-frame clips with `threads` PyTorch threads.
+    dedup=0: reference semantics incl. the 13x redundant pyramid (tester.py:122-139 on windowed input);
+    dedup=1: one pyramid per unique frame (variant ii).  Prints one JSON line with its timings."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import mm_oracle
     import mimamo_net_amd  # noqa: F401
@@ -67,7 +87,11 @@ def _cpu_worker(first_clip, n_clips, threads, out_path):
         if c:
             gray, rgb = synthetic.preprocess_host(synthetic.make_clip_u8(first_clip + c, FRAMES_PER_CLIP))
         t0 = time.time()
-        p0, p1 = mm_oracle.phase_diff_output(gray[ids][None])           # tester.py:122-139 (windowed, 13x redundant)
+        if dedup:
+            p0, p1 = mm_oracle.phase_diff_from_frames(gray, ids)
+            p0, p1 = p0[None], p1[None]
+        else:
+            p0, p1 = mm_oracle.phase_diff_output(gray[ids][None])       # tester.py:122-139 (windowed, 13x redundant)
         t1 = time.time()
         feats = mm_oracle.resnet50_pool5(resnet_sd, rgb)                # resnet50_extractor.py:74-83
         t2 = time.time()
@@ -80,12 +104,28 @@ def _cpu_worker(first_clip, n_clips, threads, out_path):
                       "frames": n_clips * FRAMES_PER_CLIP}))
 
 
-def cpu_baseline(n_clips, head_sd, resnet_sd):
+def _cpu_run(n_clips, procs, threads, dedup, out0):
+    import subprocess
+    per = max(1, n_clips // procs)
+    env = dict(os.environ, OMP_NUM_THREADS=str(threads), MKL_NUM_THREADS=str(threads))
+    ps = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-worker", str(i * per), str(per), str(threads),
+                            out0 if i == 0 else "", str(int(dedup))], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL,
+                           env=env, universal_newlines=True) for i in range(procs)]
+    recs = []
+    for pr in ps:
+        so, _ = pr.communicate()
+        recs.append(json.loads([l for l in so.splitlines() if l.startswith("{")][-1]))
+    wall = max(r["t_end"] for r in recs) - min(r["t_start"] for r in recs)
+    frames = sum(r["frames"] for r in recs)
+    return frames / wall, wall, procs * per, recs
+
+
+def cpu_baseline(n_clips, resnet_sd):
     """The oracle on the host's cores: PyTorch's intra-op pool stops scaling at ~16 threads on this path (one thread per
     logical core collapses to 0.4 frames/s on the 256-thread bench host), so the host is filled with several
     processes of a calibrated thread count each, every process working on its own clips -- the same sharding the GPU
-    path uses.  value = all frames / wall time from the first process's start of compute to the last one's end."""
-    import subprocess
+    path uses.  value = all frames / wall time from the first process's start of compute to the last one's end.
+    Both variants of BASELINE.md section 3: (i) reference-faithful (`value`), (ii) deduplicated pyramid."""
     import tempfile
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import mm_oracle
@@ -102,224 +142,404 @@ def cpu_baseline(n_clips, head_sd, resnet_sd):
         if dt < best_t:
             best, best_t = nt, dt
     procs = max(1, min(n_clips, (ncpu // 2) // best))      # physical cores (SMT pairs) / threads per process
-    per = max(1, n_clips // procs)
     tmp = tempfile.mkdtemp(prefix="mm_cpu_")
     out0 = os.path.join(tmp, "clip0.npy")
-    env = dict(os.environ, OMP_NUM_THREADS=str(best), MKL_NUM_THREADS=str(best))
-    ps = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-worker", str(i * per), str(per), str(best),
-                            out0 if i == 0 else ""], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, env=env,
-                           universal_newlines=True) for i in range(procs)]
-    recs = []
-    for pr in ps:
-        so, _ = pr.communicate()
-        recs.append(json.loads([l for l in so.splitlines() if l.startswith("{")][-1]))
-    wall = max(r["t_end"] for r in recs) - min(r["t_start"] for r in recs)
-    frames = sum(r["frames"] for r in recs)
+    v, wall, clips, recs = _cpu_run(n_clips, procs, best, False, out0)
+    v2, wall2, clips2, recs2 = _cpu_run(n_clips, procs, best, True, "")
     cpu_out = np.load(out0)
-    return {"value": frames / wall, "unit": "frames/s", "cores": procs * best, "kind": "port",
-            "sample": "%d clips x 64 frames in %d processes x %d threads (%d logical CPUs), oracle/mm_oracle.py on PyTorch-CPU "
-                      "fp32, %.1f s wall; per process: phase %.1f s, resnet50 %.1f s, head %.1f s"
-                      % (procs * per, procs, best, ncpu, wall, np.mean([r["phase"] for r in recs]),
-                         np.mean([r["resnet"] for r in recs]), np.mean([r["head"] for r in recs]))}, cpu_out
+
+    def stages(rs):
+        return "phase %.1f s, resnet50 %.1f s, head %.1f s" % (np.mean([r["phase"] for r in rs]),
+                                                                np.mean([r["resnet"] for r in rs]), np.mean([r["head"] for r in rs]))
+    return {"value": v, "unit": "frames/s", "cores": procs * best, "kind": "port", "cpu_model": cpu_model(),
+            "logical_cpus": ncpu,
+            "sample": "%d clips x 64 frames in %d processes x %d threads, oracle/mm_oracle.py on PyTorch-CPU fp32 with the "
+                      "reference's semantics (13x redundant pyramid), %.1f s wall; per process: %s"
+                      % (clips, procs, best, wall, stages(recs)),
+            "deduplicated": {"value": v2, "unit": "frames/s",
+                             "sample": "same clips/processes/threads, one pyramid per unique frame, %.1f s wall; per process: %s"
+                                       % (wall2, stages(recs2))}}, cpu_out
 
 
-def main():
-    if len(sys.argv) >= 6 and sys.argv[1] == "--cpu-worker":
-        _cpu_worker(int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), sys.argv[5])
-        return
+# ---------------------------------------------------------------------------------------------------------
+# compute back ends
+# ---------------------------------------------------------------------------------------------------------
+class HipCompute(object):
+    """The product path: HotPath on libmimamo_hip.so (fails loudly without the library or a GPU)."""
+
+    def __init__(self, args, device):
+        import mimamo_net_amd  # noqa: F401
+        from mimamo_net_amd import weights
+        from mimamo_net_amd.pipeline import HotPath
+        self.args, self.device = args, device
+        self.head_sd = weights.make_two_stream_state_dict(seed=0)
+        self.resnet_sd = weights.make_resnet50_state_dict(seed=0)
+        self.hot = HotPath(self.head_sd, self.resnet_sd, device)
+        self.hot.resnet.set_winograd(0 if args.no_winograd else args.winograd)
+        self.pool = {}          # clip content id -> row in the device-resident pool
+        self.frames_u8 = None   # [P*64,112,112,3] uint8
+        self.pre = None         # (gray, rgb) of the pool for --from-f32
+
+    def load(self, content_ids):
+        """Synthetic clips (seed 1000 + id) -> HBM, outside the timed region."""
+        from mimamo_net_amd import synthetic
+        ids = sorted(set(int(c) for c in content_ids))
+        self.pool = {c: i for i, c in enumerate(ids)}
+        clips = [synthetic.make_clip_u8(c, FRAMES_PER_CLIP) for c in ids]
+        self.frames_u8 = torch.from_numpy(np.concatenate(clips)).to(self.device)
+        if self.args.from_f32:
+            g, r = zip(*[synthetic.preprocess_host(c) for c in clips])
+            self.pre = (torch.from_numpy(np.concatenate(g)).to(self.device), torch.from_numpy(np.concatenate(r)).to(self.device))
+        self._sel = {}
+
+    def _select(self, content_ids):
+        """Frames of the step's clips: the pool itself when the step is the pool in order, else a device gather."""
+        key = tuple(content_ids)
+        sel = self._sel.get(key)
+        if sel is None:
+            slots = [self.pool[c] for c in content_ids]
+            if slots == list(range(len(self.pool))):
+                sel = False
+            else:
+                sel = (torch.tensor(slots, device=self.device, dtype=torch.int64)[:, None] * FRAMES_PER_CLIP
+                       + torch.arange(FRAMES_PER_CLIP, device=self.device)[None, :]).reshape(-1)
+            if len(self._sel) > 64:
+                self._sel.clear()
+            self._sel[key] = sel
+        srcs = self.pre if self.args.from_f32 else (self.frames_u8,)
+        return srcs if sel is False else tuple(t.index_select(0, sel) for t in srcs)
+
+    def step(self, content_ids, lanes=None):
+        ins = self._select(content_ids)
+        lengths = [FRAMES_PER_CLIP] * len(content_ids)
+        lanes = self.args.lanes if lanes is None else lanes
+        u8 = not self.args.from_f32
+        if lanes > 1:
+            return self.hot.forward_lanes(ins, lengths, lanes, independent_clips=True, from_u8=u8)
+        plan = self.hot.plan(lengths) if getattr(self, "_plan_n", None) != len(lengths) else self._plan
+        self._plan, self._plan_n = plan, len(lengths)
+        return self.hot.forward_u8(ins[0], plan, True) if u8 else self.hot.forward(ins[0], ins[1], plan, True)
+
+    def sync(self):
+        torch.cuda.synchronize()
+
+
+class StubCompute(object):
+    """Launcher / work-queue plumbing test on hosts without a GPU (`--stub-compute`): rows depend only on
+    (clip id, frame).  Never a measurement: the JSON line says data = "stub"."""
+
+    def __init__(self, args, device):
+        self.device = device
+
+    def load(self, content_ids):
+        pass
+
+    def step(self, content_ids, lanes=None):
+        c = torch.tensor(list(content_ids), dtype=torch.float32)[:, None].expand(len(content_ids), FRAMES_PER_CLIP)
+        f = torch.arange(FRAMES_PER_CLIP, dtype=torch.float32)[None, :].expand_as(c)
+        return torch.stack([c, f], -1).reshape(-1, 2).contiguous()
+
+    def sync(self):
+        pass
+
+
+# ---------------------------------------------------------------------------------------------------------
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--clips", type=int, default=32, help="64-frame clips per GPU per step")
+    ap.add_argument("--total-clips", type=int, default=0,
+                    help="size of the work queue (clips of the whole job); default: 10000 for N>1 (BASELINE configs[4]), "
+                         "--clips for N=1")
+    ap.add_argument("--whole-job", action="store_true", help="ignore --steps: walk the whole work queue once")
+    ap.add_argument("--distinct-clips", type=int, default=0,
+                    help="distinct synthetic clip contents (clip id mod this); default min(total, 2 x clips)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL; gloo only for "
-                    "plumbing tests of the multi-process path on a single GPU, together with --same-device)")
+    ap.add_argument("--no-extra", action="store_true", help="skip the direct-form / fp32-input / multi-snippet legs")
+    ap.add_argument("--extra-steps", type=int, default=5)
+    ap.add_argument("--backend", default=None, help="torch.distributed backend for N>1 (default nccl = RCCL on a GPU host; "
+                    "gloo only for plumbing tests, e.g. two ranks on one GPU with --same-device)")
     ap.add_argument("--same-device", action="store_true", help="testing only: every rank uses cuda:0")
     ap.add_argument("--force-dist", action="store_true",
-                    help="testing only: run the N>1 code path (process group, async all-gather, barrier) even with one rank, "
-                         "to exercise it over RCCL on a single-GPU box")
+                    help="testing only: create the process group (RCCL) even with one rank, to exercise the broadcast / "
+                         "all-gather path on a single-GPU box")
+    ap.add_argument("--stub-compute", action="store_true", help="testing only: no GPU work (launcher / work-queue plumbing)")
+    ap.add_argument("--dump-out", default="", help="testing only: rank 0 saves the gathered rows of the last step (.npy)")
     ap.add_argument("--no-winograd", action="store_true", help="run every 3x3 layer in the direct implicit-GEMM form")
     ap.add_argument("--winograd", type=int, default=1, help="1 = default variant (F(4x4,3x3)), 2 = F(2x2,3x3), 4 = F(4x4,3x3)")
     ap.add_argument("--lanes", type=int, default=3, help="HIP streams the clips of a step are spread over (1 = single stream)")
-    ap.add_argument("--from-u8", action="store_true",
-                    help="start every step from the raw boundary (uint8 112x112x3 aligned faces in HBM): adds the "
-                         "PIL-exact on-GPU preprocessing to the timed region")
+    ap.add_argument("--from-f32", action="store_true",
+                    help="start every step from host-preprocessed fp32 tensors (gray 48x48, RGB 224x224) instead of the "
+                         "raw uint8 boundary")
+    ap.add_argument("--from-u8", action="store_true", help="(default) start every step from uint8 112x112x3 frames in HBM")
     ap.add_argument("--cpu-clips", type=int, default=16, help="64-frame clips timed on the host for cpu_baseline (all processes together)")
-    args = ap.parse_args()
+    return ap.parse_args(argv)
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    use_dist = world > 1 or args.force_dist
-    if use_dist:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29500")
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        torch.cuda.set_device(0 if args.same_device else local_rank)
-        kw = {"device_id": torch.device("cuda", torch.cuda.current_device())} if args.backend == "nccl" else {}
-        dist.init_process_group(backend=args.backend, rank=rank, world_size=world, **kw)
-    else:
-        torch.cuda.set_device(0)
-    device = torch.device("cuda", torch.cuda.current_device())
 
+def main():
+    if len(sys.argv) >= 6 and sys.argv[1] == "--cpu-worker":
+        _cpu_worker(int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), sys.argv[5], int(sys.argv[6]) if len(sys.argv) > 6 else 0)
+        return 0
+    args = parse_args()
     import mimamo_net_amd  # noqa: F401
-    from mimamo_net_amd import _lib, weights
-    from mimamo_net_amd.pipeline import HotPath
+    from mimamo_net_amd import dist as mdist
+    _, env_w, _ = mdist.env_world()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if env_w is None and args.gpus > 1:
+        # self-spawn: one process per GPU with the torchrun environment; rank 0's stdout is the JSON line
+        code, out0 = mdist.spawn_ranks([os.path.abspath(__file__)] + sys.argv[1:], args.gpus)
+        sys.stdout.write(out0)
+        sys.stdout.flush()
+        return code
+    if env_w is not None and env_w != args.gpus:
+        raise SystemExit("bench.py: --gpus %d does not match WORLD_SIZE=%d of the launcher environment" % (args.gpus, env_w))
+    return run_rank(args)
 
-    head_sd = weights.make_two_stream_state_dict(seed=0)
-    resnet_sd = weights.make_resnet50_state_dict(seed=0)
-    hot = HotPath(head_sd, resnet_sd, device)
-    hot.resnet.set_winograd(0 if args.no_winograd else args.winograd)
-    gray, rgb = make_inputs(args.clips, rank, device)
-    plan = hot.plan([FRAMES_PER_CLIP] * args.clips)
-    n_frames = args.clips * FRAMES_PER_CLIP
 
-    frames_u8 = None
-    if args.from_u8:
-        from mimamo_net_amd import synthetic
-        frames_u8 = torch.from_numpy(np.concatenate(
-            [synthetic.make_clip_u8(rank * args.clips + c, FRAMES_PER_CLIP) for c in range(args.clips)])).to(device)
+def run_rank(args):
+    from mimamo_net_amd import dist as mdist
+    gpu = not args.stub_compute
+    if gpu and not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (torch.cuda.is_available() is False); there is no CPU path")
+    backend = args.backend or ("nccl" if gpu else "gloo")
+    _, env_w, env_local = mdist.env_world()
+    dev_index = 0 if args.same_device else env_local
+    rank, world, local_rank = mdist.init(backend, device_index=dev_index if gpu else None, force=args.force_dist)
+    if gpu:
+        torch.cuda.set_device(dev_index)
+        device = torch.device("cuda", dev_index)
+    else:
+        device = torch.device("cpu")
+    coll_dev = device if (gpu and backend == "nccl") else torch.device("cpu")
 
-    lengths = [FRAMES_PER_CLIP] * args.clips
+    # ---- the work queue: rank 0 builds it, everyone receives it (RCCL broadcast), everyone shards it the same way
+    total = args.total_clips or (10000 if world > 1 else args.clips)
+    work0 = np.stack([np.arange(total), np.full(total, FRAMES_PER_CLIP)], 1) if rank == 0 else None
+    work = mdist.broadcast_work(work0, rank, world, coll_dev)
+    assert work.shape == (total, 2) and (work[:, 1] == FRAMES_PER_CLIP).all()
+    mine = [int(work[i, 0]) for i in mdist.shard(total, rank, world)]          # clip ids of this rank, queue order
+    if not mine:
+        raise SystemExit("rank %d has no clips: --total-clips %d < %d ranks" % (rank, total, world))
+    distinct = args.distinct_clips or min(total, 2 * args.clips)
+    per_step = min(args.clips, len(mine))
+    if args.whole_job:
+        steps_all = [mine[i:i + args.clips] for i in range(0, len(mine), args.clips)]
+        n_steps = int(mdist.max_over_ranks(len(steps_all), coll_dev))
+        warm = [steps_all[0]] * args.warmup
+        timed = steps_all + [[]] * (n_steps - len(steps_all))
+    else:
+        n_steps = args.steps
+        seq = [[mine[(s * per_step + k) % len(mine)] for k in range(per_step)] for s in range(args.warmup + n_steps)]
+        warm, timed = seq[:args.warmup], seq[args.warmup:]
+    content = lambda ids: [c % distinct for c in ids]                         # noqa: E731
 
-    # N>1: the [frames,2] results of a step are all-gathered (8 B/frame, the only collective on the path).  It is issued
-    # asynchronously on RCCL's stream and only waited for one step later, so a rank never stalls on a slower peer
-    # inside a step -- ranks are independent shards and the job time is the slowest rank's, not a sum of per-step maxima.
+    comp = (StubCompute if args.stub_compute else HipCompute)(args, device)
+    comp.load({c % distinct for s in warm + timed for c in s})
+
+    # The [frames,2] results of a step are all-gathered (8 B/frame, the only collective besides the queue broadcast).  It
+    # is issued asynchronously on RCCL's stream and only waited for one step later, so a rank never stalls on a slower
+    # peer inside a step -- ranks are independent shards and the job time is the slowest rank's, not a sum of maxima.
     pending = []
+    last = {}
 
-    def step():
-        if args.lanes > 1:
-            ins = (frames_u8,) if frames_u8 is not None else (gray, rgb)
-            out = hot.forward_lanes(ins, lengths, args.lanes, independent_clips=True, from_u8=frames_u8 is not None)
-        elif frames_u8 is not None:
-            out = hot.forward_u8(frames_u8, plan, independent_clips=True)
+    def drain():
+        while pending:
+            h, bufs, keep = pending.pop()
+            if h is not None:
+                h.wait()
+            last["gathered"] = bufs
+
+    def step(ids):
+        out = comp.step(content(ids)) if ids else torch.zeros((0, 2), device=device)
+        if world > 1 or args.force_dist:
+            drain()
+            rows = args.clips * FRAMES_PER_CLIP
+            if out.shape[0] != rows:      # ragged tail of the queue (--whole-job): pad to the step shape, NaN = no clip
+                pad = torch.full((rows, 2), float("nan"), dtype=out.dtype, device=out.device)
+                pad[: out.shape[0]] = out
+                out_g = pad
+            else:
+                out_g = out
+            h, bufs = mdist.all_gather_rows_async(out_g, world)
+            pending.append((h, bufs, out_g))
         else:
-            out = hot.forward(gray, rgb, plan, independent_clips=True)  # [frames, 2]
-        if use_dist:
-            import torch.distributed as dist
-            while pending:
-                pending.pop()[0].wait()
-            gathered = [torch.empty_like(out) for _ in range(world)]
-            pending.append((dist.all_gather(gathered, out, async_op=True), gathered, out))
+            last["gathered"] = [out]
         return out
 
     def fence():
-        if use_dist:
-            import torch.distributed as dist
-            while pending:
-                pending.pop()[0].wait()
-            dist.barrier()
-        torch.cuda.synchronize()
+        drain()
+        mdist.barrier()
+        comp.sync()
 
     with torch.no_grad():
-        for _ in range(args.warmup):
-            out = step()
+        for ids in warm:
+            out = step(ids)
         fence()
         t0 = time.perf_counter()
-        for _ in range(args.steps):
-            out = step()
+        for ids in timed:
+            out = step(ids)
         fence()
         dt = time.perf_counter() - t0
-    if use_dist:
-        import torch.distributed as dist
-        t = torch.tensor([dt], device=device, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-    assert torch.isfinite(out).all()
+    dt = mdist.max_over_ranks(dt, coll_dev)
+    frames_rank = sum(len(s) for s in timed) * FRAMES_PER_CLIP
+    frames_all = total * FRAMES_PER_CLIP if args.whole_job else world * frames_rank
+    if gpu:
+        assert torch.isfinite(out).all()
+    if args.dump_out and rank == 0:
+        np.save(args.dump_out, torch.cat([t.cpu() for t in last["gathered"]], 0).numpy())
+
+    n_frames = per_step * FRAMES_PER_CLIP
+    result = {
+        "metric": "face-frames/sec end-to-end (phase-diff + ResNet50 + 2-stream GRU), 64-frame clips",
+        "value": frames_all / dt,
+        "unit": "frames/s",
+        "n_gpus": world,
+        "steps": n_steps,
+        "warmup": args.warmup,
+        "ms_per_step": dt / max(n_steps, 1) * 1e3,
+        "higher_is_better": True,
+        "scaling": "strong" if args.whole_job else "weak",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "stub (no GPU work: launcher plumbing test)" if args.stub_compute else "synthetic",
+        "config": {"workload": ("full two-stream hot path (BASELINE configs[%d]): %d clips x 64 frames per GPU per step from "
+                                "uint8 112x112x3 aligned-face frames resident in HBM (PIL-exact on-GPU preprocessing, pyramid + "
+                                "phase difference, ResNet50 pool5, two-stream GRU head inside the timed region); random-init "
+                                "weights of the reference architecture" % (4 if world > 1 else 3, per_step))
+                               if not args.from_f32 else
+                               ("full two-stream hot path (BASELINE configs[3]) from host-preprocessed fp32 tensors (gray 48x48 + "
+                                "RGB 224x224): %d clips x 64 frames per GPU per step" % per_step),
+                   "input": "preprocessed fp32 tensors" if args.from_f32 else "uint8 112x112x3 frames",
+                   "lanes": args.lanes, "clips_per_gpu": per_step, "frames_per_step_per_gpu": n_frames,
+                   "work_queue": {"total_clips": total, "clips_this_rank": len(mine), "distinct_clip_contents": distinct,
+                                  "broadcast": backend if (world > 1 or args.force_dist) else None,
+                                  "whole_job": bool(args.whole_job)},
+                   "parallelism": "videos sharded, dp%d" % world},
+    }
+    if args.stub_compute:
+        if rank == 0:
+            print(json.dumps(result))
+        mdist.shutdown()
+        return 0
 
     # ---- roofline leg: hipEvent-timed launches of one more step (same stream), by kernel category
+    from mimamo_net_amd import _lib
     L = _lib.lib()
     ms = (ctypes.c_double * 4)()
-    work = (ctypes.c_double * 4)()
+    work_ = (ctypes.c_double * 4)()
     launches = (ctypes.c_int64 * 4)()
+    ids0 = content(timed[0] if timed[0] else warm[0] if warm else mine[:per_step])
     with torch.no_grad():
+        comp.step(ids0, lanes=1)
+        comp.sync()
         L.mm_profile_begin()
         # single stream for this leg: with several lanes in flight a kernel's event bracket also counts the time it
         # shares the GPU with another lane's kernel, which would under-state the per-kernel rate
-        if frames_u8 is not None:
-            hot.forward_u8(frames_u8, plan, independent_clips=True)
-        else:
-            hot.forward(gray, rgb, plan, independent_clips=True)
-        rc = L.mm_profile_end(ms, work, launches)
+        comp.step(ids0, lanes=1)
+        rc = L.mm_profile_end(ms, work_, launches)
     assert rc == 0
-    conv_tflops = work[0] / (ms[0] * 1e-3) / 1e12
+    conv_tflops = work_[0] / (ms[0] * 1e-3) / 1e12
     phase_ms = ms[1] + ms[2]
-    phase_gbs = (work[1] + work[2]) / (phase_ms * 1e-3) / 1e9
+    phase_gbs = (work_[1] + work_[2]) / (phase_ms * 1e-3) / 1e9
 
-    # HBM traffic of the conv engine cannot be read live (PMC counters need rocprofv3): tools/pmc_bench_traffic.sh
-    # measures it for this exact command and the summary is committed under profiles/; it is reported here only
-    # when it was taken at the same clips-per-GPU.
-    traffic = None
-    tpath = os.path.join(ROOT, "profiles", "r01_conv_traffic_%dclips.json" % args.clips)
-    if os.path.exists(tpath):
-        with open(tpath) as f:
+    def committed_traffic(name):
+        """PMC HBM traffic from profiles/ -- only if it was measured on these kernels at this step size."""
+        path = os.path.join(ROOT, "profiles", name % per_step)
+        if not os.path.exists(path):
+            return None
+        with open(path) as f:
             tj = json.load(f)
-        if tj.get("clips_per_gpu") == args.clips:
-            traffic = tj["bytes_per_step"]
+        if tj.get("kernel_source_hash") != kernel_source_hash() or tj.get("clips_per_gpu") != per_step:
+            return None
+        return tj.get("bytes_per_step")
 
-    ptraffic = None
-    ppath = os.path.join(ROOT, "profiles", "r01_phase_traffic_%dclips.json" % args.clips)
-    if os.path.exists(ppath):
-        with open(ppath) as f:
-            ptraffic = json.load(f).get("bytes_per_step")
+    traffic = committed_traffic("r02_conv_traffic_%dclips.json")
+    ptraffic = committed_traffic("r02_phase_traffic_%dclips.json")
+    wino = 0 if args.no_winograd else {1: 4}.get(args.winograd, args.winograd)
+    result["roofline"] = {
+        "bound": "mfma", "kernel": "conv_mfma_kernel (fp32 implicit-GEMM conv/GEMM engine, all %d launches of one step)" % launches[0],
+        "achieved": conv_tflops, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+        "frac": conv_tflops / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic,
+        "traffic_note": ("HBM bytes per step over all conv launches, rocprofv3 PMC (2*FETCH_SIZE + WRITE_SIZE)*1024, from "
+                         "profiles/ (same kernel sources, not live)") if traffic else
+                        "no PMC summary under profiles/ for these kernel sources (hash %s)" % kernel_source_hash(),
+        "flops_per_step": work_[0], "ms_per_step": ms[0], "launches_per_step": int(launches[0]),
+        "note": "flops = executed on the matrix cores; with Winograd F(4x4,3x3) (or F(2x2,3x3)) on the stride-1 3x3 layers of conv2_x..conv5_x "
+                "that is less than the direct-form count (algorithmic_direct_flops_per_step = 8.108 GFLOP/frame)",
+        "algorithmic_direct_flops_per_step": 8.108e9 * n_frames,
+        # SURVEY 8(d) figure (direct-form 8.108 GFLOP/frame) over the conv launches AND the Winograd transforms
+        "algorithmic_equiv_tflops": 8.108e9 * n_frames / ((ms[0] + ms[3]) * 1e-3) / 1e12,
+        "algorithmic_equiv_frac": 8.108e9 * n_frames / ((ms[0] + ms[3]) * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS,
+        "winograd": wino,
+        "winograd_transforms": {"ms_per_step": ms[3], "bytes_per_step": work_[3], "launches_per_step": int(launches[3]),
+                                "GB_per_s": (work_[3] / (ms[3] * 1e-3) / 1e9) if ms[3] > 0 else None}}
+    result["roofline_phase"] = {"bound": "hbm", "kernel": "pyramid_kernel + phase_window_kernel<48|24>",
+                                "achieved": phase_gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": phase_gbs / PEAK_HBM_GBS,
+                                "traffic": ptraffic, "bytes_per_step": work_[1] + work_[2], "ms_per_step": phase_ms,
+                                "ms_pyramid": ms[1], "ms_window": ms[2]}
 
-    result = {
-        "metric": "face-frames/sec end-to-end (phase-diff + ResNet50 + 2-stream GRU), 64-frame clips",
-        "value": world * n_frames * args.steps / dt,
-        "unit": "frames/s",
-        "n_gpus": world,
-        "steps": args.steps,
-        "warmup": args.warmup,
-        "ms_per_step": dt / args.steps * 1e3,
-        "higher_is_better": True,
-        "scaling": "weak",
-        "vs_baseline": None,
-        "dtype": "f32",
-        "data": "synthetic",
-        "config": {"workload": "full two-stream hot path (BASELINE configs[3]): %d clips x 64 frames per GPU per step; "
-                               "gray 48x48 + RGB 224x224 fp32 resident in HBM; random-init weights of the reference architecture"
-                               % args.clips,
-                   "input": "uint8 112x112x3 frames (on-GPU PIL-exact preprocessing in the timed region)" if args.from_u8
-                            else "preprocessed fp32 tensors",
-                   "lanes": args.lanes,
-                   "clips_per_gpu": args.clips, "frames_per_step_per_gpu": n_frames, "parallelism": "videos sharded, dp%d" % world},
-        "roofline": {"bound": "mfma", "kernel": "conv_mfma_kernel (fp32 implicit-GEMM conv/GEMM engine, all %d launches of one step)" % launches[0],
-                     "achieved": conv_tflops, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                     "frac": conv_tflops / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic,
-                     "traffic_note": "HBM bytes per step over all conv launches, rocprofv3 PMC (2*FETCH_SIZE + WRITE_SIZE)*1024, "
-                                     "from profiles/ (not live)" if traffic else None,
-                     "flops_per_step": work[0], "ms_per_step": ms[0], "launches_per_step": int(launches[0]),
-                     "note": "flops = executed on the matrix cores; with Winograd F(4x4,3x3) (or F(2x2,3x3)) on the stride-1 3x3 layers of conv2_x..conv5_x "
-                             "that is less than the direct-form count (algorithmic_direct_flops_per_step = 8.108 GFLOP/frame)",
-                     "algorithmic_direct_flops_per_step": 8.108e9 * n_frames,
-                     # SURVEY 8(d) figure (direct-form 8.108 GFLOP/frame) over the conv launches AND the Winograd transforms
-                     "algorithmic_equiv_tflops": 8.108e9 * n_frames / ((ms[0] + ms[3]) * 1e-3) / 1e12,
-                     "algorithmic_equiv_frac": 8.108e9 * n_frames / ((ms[0] + ms[3]) * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS,
-                     "winograd": (0 if args.no_winograd else {1: 4}.get(args.winograd, args.winograd)),
-                     "winograd_transforms": {"ms_per_step": ms[3], "bytes_per_step": work[3], "launches_per_step": int(launches[3]),
-                                             "GB_per_s": (work[3] / (ms[3] * 1e-3) / 1e9) if ms[3] > 0 else None}},
-        "roofline_phase": {"bound": "hbm", "kernel": "pyramid_kernel + phase_window_kernel<48|24>",
-                           "achieved": phase_gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": phase_gbs / PEAK_HBM_GBS,
-                           "traffic": ptraffic, "bytes_per_step": work[1] + work[2], "ms_per_step": phase_ms,
-                           "ms_pyramid": ms[1], "ms_window": ms[2]},
-    }
+    if rank == 0 and world == 1 and not args.no_extra:
+        result["extra"] = extra_legs(args, comp, ids0, n_frames)
+
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
-            cb, cpu_out = cpu_baseline(args.cpu_clips, head_sd, resnet_sd)
+            cb, cpu_out = cpu_baseline(args.cpu_clips, comp.resnet_sd)
             result["cpu_baseline"] = cb
-            # clip 0 of the CPU sample is clip 0 of this rank: report the parity of the two paths next to the numbers
-            gpu0 = out[:FRAMES_PER_CLIP].cpu().numpy()
-            result["parity_vs_cpu_sample"] = {"max_abs_err_valence_arousal": float(np.abs(gpu0 - cpu_out[0]).max()),
-                                              "tolerance": 1e-4}
+            # clip 0 of the CPU sample is content id 0: report the parity of the two paths next to the numbers
+            with torch.no_grad():
+                gpu0 = comp.step([0], lanes=1).cpu().numpy() if 0 in comp.pool else None
+            if gpu0 is not None:
+                result["parity_vs_cpu_sample"] = {"max_abs_err_valence_arousal": float(np.abs(gpu0 - cpu_out[0]).max()),
+                                                  "tolerance": 1e-4}
         else:
             result["cpu_baseline"] = None
         print(json.dumps(result))
-    if use_dist:
-        import torch.distributed as dist
-        dist.destroy_process_group()
+    mdist.shutdown()
+    return 0
+
+
+def extra_legs(args, comp, ids0, n_frames):
+    """N=1 only, after the headline: the same step (a) in direct form (no Winograd), (b) on multi-snippet videos of the reference's run_example shape (309 frames -> 5 snippets, GRU seq_len 5,
+    tail snippet overwriting; api/run_example.py:7-13, snippet_sampler.py:112-126)."""
+    from mimamo_net_amd import synthetic
+    hot, K = comp.hot, max(1, args.extra_steps)
+
+    def timeit(fn):
+        with torch.no_grad():
+            fn()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(K):
+                fn()
+            torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / K
+
+    ex = {"steps": K}
+    wino = 0 if args.no_winograd else args.winograd
+    hot.resnet.set_winograd(0)
+    dt = timeit(lambda: comp.step(ids0))
+    hot.resnet.set_winograd(wino)
+    ex["direct_form"] = {"value": n_frames / dt, "unit": "frames/s", "ms_per_step": dt * 1e3,
+                         "what": "same step with every 3x3 layer as a direct implicit GEMM (no Winograd)"}
+    # (b) multi-snippet videos
+    nv = max(1, round(n_frames / EXAMPLE_VIDEO_FRAMES))
+    vids = torch.from_numpy(np.concatenate([synthetic.make_clip_u8(5000 + v, EXAMPLE_VIDEO_FRAMES) for v in range(nv)])).to(comp.device)
+    lengths = [EXAMPLE_VIDEO_FRAMES] * nv
+    dt = timeit(lambda: hot.forward_lanes((vids,), lengths, min(args.lanes, nv), from_u8=True))
+    plan = hot.plan(lengths)
+    ex["multi_snippet"] = {"value": nv * EXAMPLE_VIDEO_FRAMES / dt, "unit": "frames/s", "ms_per_step": dt * 1e3,
+                           "videos_per_step": nv, "frames_per_video": EXAMPLE_VIDEO_FRAMES,
+                           "snippets_per_video": len(plan["videos"][0]["ranges"]), "gru_seq_len": plan["groups"][0]["bs"],
+                           "head_calls_per_step": len(plan["groups"]) if args.lanes <= 1 else None,
+                           "what": "uint8 videos of the reference's run_example length; the GRU runs over each video's "
+                                   "snippets; unique frames counted once (snippet rows: %d per video)"
+                                   % (len(plan["videos"][0]["ranges"]) * plan["videos"][0]["T"])}
+    del vids
+    return ex
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

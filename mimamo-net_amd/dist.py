@@ -1,33 +1,63 @@
 """Multi-GPU scaling: videos are independent units, so they shard across ranks with NO collective on the
 data path.  One process per GPU (`torch.distributed`, backend "nccl" = RCCL over xGMI on
-ROCm; "gloo" in the CPU tests).  The only exchange is the final gather of [frames, 2] fp32 results
-(8 bytes per frame) so every rank -- or just rank 0 -- can assemble the per-video tables.
+ROCm; "gloo" in the CPU tests).  The only exchanges are the work-queue broadcast (rank 0 -> all: the list of
+videos and their lengths, a few bytes per video) and the gather of [frames, 2] fp32 results (8 bytes per
+frame) so every rank -- or just rank 0 -- can assemble the per-video tables.  The atomic unit is one video's
+snippet batch (api/tester.py:69-72): a video is never split across ranks.
 
 The reference is single-process / single-device (api/steerable/utils.py:34-50); this module is the build's
 addition, not a port of anything.
 """
 import os
+import socket
+import subprocess
+import sys
 
 import numpy as np
 import torch
 
 
-def init(backend=None):
-    """Initialise torch.distributed from the torchrun environment.  Returns (rank, world, local_rank)."""
+def env_world():
+    """(rank, world, local_rank) from the torchrun environment; world is None when WORLD_SIZE is unset."""
+    w = os.environ.get("WORLD_SIZE")
+    return int(os.environ.get("RANK", "0")), (int(w) if w is not None else None), int(os.environ.get("LOCAL_RANK", "0"))
+
+
+def init(backend=None, device_index=None, force=False):
+    """Initialise torch.distributed from the torchrun environment.  Returns (rank, world, local_rank).
+
+    backend: "nccl" (RCCL; default when a GPU is present) or "gloo".  device_index: the GPU this rank binds to
+    (default LOCAL_RANK).  force: create the process group even for world == 1 (exercises RCCL on a 1-GPU box)."""
     import torch.distributed as dist
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1 and not dist.is_initialized():
+    rank, world, local_rank = env_world()
+    world = 1 if world is None else world
+    if (world > 1 or force) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC only on these hosts
+        os.environ.setdefault("RANK", str(rank))
+        os.environ.setdefault("WORLD_SIZE", str(world))
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
-        if backend == "nccl":
-            torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+        kw = {}
+        if torch.cuda.is_available():
+            torch.cuda.set_device(local_rank if device_index is None else device_index)
+            if backend == "nccl":
+                kw["device_id"] = torch.device("cuda", torch.cuda.current_device())
+        dist.init_process_group(backend=backend, rank=rank, world_size=world, **kw)
     return rank, world, local_rank
+
+
+def active():
+    import torch.distributed as dist
+    return dist.is_available() and dist.is_initialized()
+
+
+def _staged(t):
+    """gloo has no device all_gather/barrier: stage device tensors through the host for it (tests only; RCCL moves
+    them device to device)."""
+    import torch.distributed as dist
+    return t.is_cuda and dist.get_backend() == "gloo"
 
 
 def shard(n_videos, rank, world, lengths=None):
@@ -46,11 +76,49 @@ def shard(n_videos, rank, world, lengths=None):
     return sorted(mine)
 
 
+def broadcast_work(work, rank, world, device="cpu"):
+    """The work queue: rank 0 holds `work` = int64 array [n, k] (one row per video: id, length, ...); every rank
+    returns the same array.  Two broadcasts (shape, payload) from rank 0; on RCCL they run device to device."""
+    if world == 1 and not active():
+        return np.ascontiguousarray(np.asarray(work, dtype=np.int64))
+    import torch.distributed as dist
+    dev = torch.device(device)
+    if rank == 0:
+        w = np.ascontiguousarray(np.asarray(work, dtype=np.int64))
+        assert w.ndim == 2
+        shape = torch.tensor(list(w.shape), dtype=torch.int64, device=dev)
+    else:
+        shape = torch.zeros(2, dtype=torch.int64, device=dev)
+    dist.broadcast(shape, src=0)
+    n, k = int(shape[0].item()), int(shape[1].item())
+    payload = torch.from_numpy(w).to(dev) if rank == 0 else torch.empty((n, k), dtype=torch.int64, device=dev)
+    dist.broadcast(payload, src=0)
+    return payload.cpu().numpy()
+
+
+def all_gather_rows_async(local_rows, world):
+    """Equal-shape all-gather of [n, C] rows, asynchronous: returns (work handle or None, list of per-rank tensors).
+    The caller waits on the handle before reading the list (bench: one step later, so a rank never stalls on a
+    slower peer inside a step)."""
+    if not active():
+        return None, [local_rows]
+    import torch.distributed as dist
+    if _staged(local_rows):
+        host = local_rows.cpu()
+        bufs = [torch.empty_like(host) for _ in range(world)]
+        dist.all_gather(bufs, host)
+        return None, bufs
+    bufs = [torch.empty_like(local_rows) for _ in range(world)]
+    return dist.all_gather(bufs, local_rows, async_op=True), bufs
+
+
 def gather_rows(local_rows, world, rank, max_rows=None):
     """All-gather variable-length [n_r, C] float tensors; returns the list of per-rank tensors (on every rank)."""
-    if world == 1:
+    if world == 1 and not active():
         return [local_rows]
     import torch.distributed as dist
+    if _staged(local_rows):
+        local_rows = local_rows.cpu()
     n = torch.tensor([local_rows.shape[0]], dtype=torch.int64, device=local_rows.device)
     counts = [torch.zeros_like(n) for _ in range(world)]
     dist.all_gather(counts, n)
@@ -61,6 +129,30 @@ def gather_rows(local_rows, world, rank, max_rows=None):
     bufs = [torch.empty_like(pad) for _ in range(world)]
     dist.all_gather(bufs, pad)
     return [b[:c] for b, c in zip(bufs, counts)]
+
+
+def max_over_ranks(value, device="cpu"):
+    """MAX all-reduce of one float (the job time is the slowest rank's)."""
+    if not active():
+        return float(value)
+    import torch.distributed as dist
+    t = torch.tensor([float(value)], dtype=torch.float64, device=torch.device(device))
+    if _staged(t):
+        t = t.cpu()
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def barrier():
+    if active():
+        import torch.distributed as dist
+        dist.barrier()
+
+
+def shutdown():
+    if active():
+        import torch.distributed as dist
+        dist.destroy_process_group()
 
 
 def run_sharded(video_lengths, compute_rows, rank, world, device="cpu"):
@@ -78,3 +170,65 @@ def run_sharded(video_lengths, compute_rows, rank, world, device="cpu"):
             off += video_lengths[i]
         assert off == part.shape[0]
     return out
+
+
+# ---- launcher: one process per GPU -------------------------------------------------------------------------
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def spawn_ranks(argv, n_ranks, env=None, timeout=None):
+    """Start `n_ranks` copies of `python argv...` on this node, one per GPU, with the torchrun environment
+    (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR=127.0.0.1 / MASTER_PORT), wait for all of them and return
+    (exit code, rank 0's stdout).  If a rank fails, the others (possibly blocked in a collective) are terminated
+    by PID and the failing rank's stderr tail is written to this process's stderr."""
+    import tempfile
+    import time
+    base = dict(os.environ if env is None else env)
+    base.update({"WORLD_SIZE": str(n_ranks), "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(free_port()),
+                 "HSA_ENABLE_IPC_MODE_LEGACY": base.get("HSA_ENABLE_IPC_MODE_LEGACY", "0")})
+    tmp = tempfile.mkdtemp(prefix="mm_ranks_")
+    procs, files = [], []
+    for r in range(n_ranks):
+        e = dict(base, RANK=str(r), LOCAL_RANK=str(r))
+        fo, fe = open(os.path.join(tmp, "out%d" % r), "w+"), open(os.path.join(tmp, "err%d" % r), "w+")
+        files.append((fo, fe))
+        procs.append(subprocess.Popen([sys.executable] + list(argv), env=e, stdout=fo, stderr=fe))
+    code, t0 = 0, time.time()
+    try:
+        while True:
+            states = [p.poll() for p in procs]
+            bad = [r for r, s in enumerate(states) if s not in (None, 0)]
+            if bad:
+                code = states[bad[0]]
+                files[bad[0]][1].seek(0)
+                sys.stderr.write("[rank %d exited with %d]\n%s\n" % (bad[0], code, files[bad[0]][1].read()[-4000:]))
+                break
+            if all(s == 0 for s in states):
+                break
+            if timeout is not None and time.time() - t0 > timeout:
+                code = 124
+                sys.stderr.write("[spawn_ranks: timeout after %.0f s]\n" % timeout)
+                break
+            time.sleep(0.05)
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.terminate()
+        for p in procs:
+            try:
+                p.wait(timeout=30)
+            except subprocess.TimeoutExpired:
+                p.kill()
+    files[0][0].seek(0)
+    out0 = files[0][0].read()
+    for fo, fe in files:
+        fo.close()
+        fe.close()
+    import shutil
+    shutil.rmtree(tmp, ignore_errors=True)
+    return code, out0

@@ -13,9 +13,16 @@ from . import _lib, weights
 
 class Two_Stream_RNN(object):
     def __init__(self, mlp_hidden_units=[2048, 256, 256], dropout=0.5, label_name='arousal_valence', num_phase=12):
-        if list(mlp_hidden_units) != [2048, 256, 256] or label_name != 'arousal_valence' or num_phase != 12:
-            raise NotImplementedError("this build implements the published configuration "
-                                      "(mlp [2048,256,256], arousal_valence, num_phase=12; api/tester.py:45)")
+        """Arguments as api/mimamo_net.py:97-122.  label_name in {'arousal', 'valence', 'arousal_valence'} sets the width
+        of the output layer (len(label_name.split('_')), :120-122).  mlp_hidden_units other than the published
+        [2048, 256, 256] (api/tester.py:45) and num_phase != 12 are not built into the library."""
+        if list(mlp_hidden_units) != [2048, 256, 256] or num_phase != 12:
+            raise NotImplementedError("this build implements the published trunk (mlp [2048,256,256], num_phase=12; "
+                                      "api/tester.py:45)")
+        if label_name not in ('arousal', 'valence', 'arousal_valence'):
+            raise ValueError("label_name must be one of 'arousal', 'valence', 'arousal_valence' (api/mimamo_net.py:106)")
+        self.label_name = label_name
+        self.n_out = len(label_name.split("_"))
         self.num_phase = num_phase
         self.training = False
         self._handle = None
@@ -37,8 +44,13 @@ class Two_Stream_RNN(object):
             extra = [k for k in state_dict if k not in known]
             if extra:
                 raise RuntimeError("Error(s) in loading state_dict for Two_Stream_RNN: Unexpected key(s): %s" % extra[:4])
+        for k in ("classifier.1.weight", "classifier.1.bias", "classifier.2.weight", "classifier.2.bias",
+                  "classifier.2.running_mean", "classifier.2.running_var"):
+            if tuple(state_dict[k].shape)[0] != self.n_out:
+                raise RuntimeError("Error(s) in loading state_dict for Two_Stream_RNN: size mismatch for %s: checkpoint has %d "
+                                   "outputs, label_name=%r needs %d" % (k, tuple(state_dict[k].shape)[0], self.label_name, self.n_out))
         self._state = {k: v for k, v in state_dict.items()}
-        self._blob = weights.two_stream_blob(state_dict)
+        self._blob = weights.two_stream_blob(weights.widen_classifier(state_dict) if self.n_out == 1 else state_dict)
         self._release()
         return self
 
@@ -95,7 +107,8 @@ class Two_Stream_RNN(object):
 
     # -- forward ---------------------------------------------------------------------------------
     def forward(self, phase_data, rgb_data, phase_layout="nchw"):
-        """phase_data = [phase_0 [bs,T,24,48,48], phase_1 [bs,T,24,24,24]], rgb_data [bs,T,2048] -> [bs,T,2].
+        """phase_data = [phase_0 [bs,T,24,48,48], phase_1 [bs,T,24,24,24]], rgb_data [bs,T,2048] -> [bs,T,n_out]
+        (n_out = 2 for 'arousal_valence', 1 for 'arousal' / 'valence').
 
         phase_layout: "nchw" (reference), "nhwc" ([bs*T,48,48,24] / [bs*T,24,24,24]) or "nhwc_cat"
         (phase_1 already at channels 64..87 of a [bs*T,24,24,88] buffer, completed in place).
@@ -129,6 +142,6 @@ class Two_Stream_RNN(object):
         rc = L.mm_head_forward(h, _lib.ptr(phase_0), _lib.ptr(phase_1), mode, _lib.ptr(rgb), bs, T, _lib.ptr(out),
                                _lib.ptr(ws), need, _lib.current_stream())
         _lib.check(rc, "mm_head_forward")
-        return out
+        return out if self.n_out == 2 else out[..., :1].contiguous()
 
     __call__ = forward

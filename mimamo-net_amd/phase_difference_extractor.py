@@ -5,6 +5,7 @@ libmimamo_hip.so (csrc/pyramid.hip, csrc/phase_window.hip) through the C ABI.  T
 on a ROCm device ("cuda"); there is no CPU fallback.
 """
 import ctypes
+import weakref
 
 import torch
 
@@ -29,6 +30,8 @@ class Phase_Difference_Extractor(object):
         self._handle = None
         self._size = None
         self._ids_cache = {}
+        self._ws = {}          # per-stream workspace of the fused path (pyramid planes, 46 KB per unique frame)
+        self._ids_ok = {}      # window-id tables already range-checked: id(tensor) -> (weakref, (version, N))
         self._general = None   # SCFpyr_PyTorch for configurations outside the fused kernels
 
     def _levels(self):
@@ -143,22 +146,40 @@ class Phase_Difference_Extractor(object):
         return out
 
     # -- fused fast path (not in the reference API) ---------------------------------------
-    def phase_diff_frames(self, frames, window_ids, nhwc=False, out1_cstride=None, out1_coffset=0):
+    def phase_diff_frames(self, frames, window_ids, nhwc=False, out1_cstride=None, out1_coffset=0, ids_checked=False):
         """De-duplicated driver: unique frames [N, W, W] + window ids [J, 13] (int32, clamped frame indices,
         api/sampler/snippet_sampler.py:144-152) -> (phase_0 [J,24,W,W], phase_1 [J,24,W/2,W/2]).
 
         Builds each frame's pyramid once instead of once per window that contains it (13x less work than
         Tester.phase_diff_output, identical results because the pyramid is per-frame -- quirk Q3).
         nhwc=True writes channels-last tensors ([J,W,W,24], [J,W/2,W/2,out1_cstride] with the 24 channels
-        at out1_coffset) for the head's conv engine."""
+        at out1_coffset) for the head's conv engine.
+        The ids index planes of the N-frame workspace: they are range-checked on the host the first time a table is
+        seen (one device->host read, cached per table); ids_checked=True skips that for tables the caller built
+        from the same frame count (HotPath.plan)."""
         self._check_input(frames, 3, "frames")
         N, W, _ = frames.shape
         J = window_ids.shape[0]
         assert window_ids.dtype == torch.int32 and window_ids.is_cuda and tuple(window_ids.shape) == (J, 13)
+        if not ids_checked and J > 0:
+            hit = self._ids_ok.get(id(window_ids))
+            if not (hit is not None and hit[0]() is window_ids and hit[1] == (window_ids._version, N)):
+                lo, hi = int(window_ids.min().item()), int(window_ids.max().item())
+                if lo < 0 or hi >= N:
+                    raise ValueError("window_ids must index the %d frames handed over (found %d..%d)" % (N, lo, hi))
+                if len(self._ids_ok) > 64:
+                    self._ids_ok.clear()
+                self._ids_ok[id(window_ids)] = (weakref.ref(window_ids), (window_ids._version, N))
         h = self._get(W)
         L = _lib.lib()
         ws_bytes = L.mm_phase_workspace_bytes(h, N)
-        ws = torch.empty((ws_bytes // 4,), dtype=torch.float32, device=frames.device)
+        skey = torch.cuda.current_stream().cuda_stream
+        ws = self._ws.get(skey)
+        if ws is None or ws.numel() * 4 < ws_bytes or ws.device != frames.device:
+            self._ws[skey] = None
+            if len(self._ws) > 8:
+                self._ws = {}
+            ws = self._ws[skey] = torch.empty((ws_bytes // 4,), dtype=torch.float32, device=frames.device)
         C = 2 * 12
         if nhwc:
             cs1 = C if out1_cstride is None else out1_cstride

@@ -5,6 +5,12 @@ without the disk round trips (.npy features, re-opened BMPs) and without the 13x
     gray frames [N,48,48] --pyramid (once per frame)--> window kernel --> phase_0 / phase_1 (NHWC)
     rgb  frames [N,3,224,224] --ResNet50 trunk--> pool5 [N,2048]
     head(phase_0, phase_1, pool5) per video (GRU over that video's snippets) --> [frames, 2]
+
+Memory is bounded by the chunk sizes, not by the video length: the reference streams 64 frames at a time
+(api/resnet50_extractor.py:56-60, api/tester.py:69-72); here preprocessing + ResNet50 run over at most
+`max_frames_per_call` frames per call (0.8 MB of NHWC4 input + 17.3 MB of activations per frame) and the phase
+stage + head over row groups of at most `batch_size` snippets, so an hour-long video needs the same workspaces as
+a one-minute one plus 8 KB + 9 KB per frame for its features and gray frames.
 """
 import numpy as np
 import torch
@@ -17,59 +23,135 @@ from .resnet50_extractor import Resnet50_Extractor
 
 class HotPath(object):
     def __init__(self, head_state_dict, resnet_state_dict, device=None, length=64, stride=64, num_phase=12,
-                 batch_size=64):
+                 batch_size=64, max_frames_per_call=4096):
         self.device = torch.device('cuda', torch.cuda.current_device()) if device is None else torch.device(device)
         self.length, self.stride, self.num_phase, self.batch_size = length, stride, num_phase, batch_size
+        self.max_frames_per_call = int(max_frames_per_call)
         self.pde = Phase_Difference_Extractor(4, 2, 2, [1, 2], False)
-        self.resnet = Resnet50_Extractor(state_dict=resnet_state_dict, device=self.device)
+        self.resnet = Resnet50_Extractor(state_dict=resnet_state_dict, device=self.device,
+                                         max_frames_per_call=self.max_frames_per_call)
         self.head = Two_Stream_RNN().load_state_dict(head_state_dict).eval().to(self.device)
         self._pre = None
 
     # ---- index plan for a set of videos (host, once) ---------------------------------------------
     def plan(self, video_lengths):
-        """Frames of all videos are stacked along dim 0.  Returns a dict with, per video, its snippet
-        ranges, and the global window-id table of every snippet frame (in snippet order)."""
-        ids, vids, off = [], [], 0
+        """Frames of all videos are stacked along dim 0.  Returns a dict with, per video, its snippet ranges and
+        the position of its rows in the [rows, 2] result (snippet order, as the reference's sampler emits them),
+        and the row GROUPS the phase stage + head are run over.
+
+        A group is one head call: the GRU's recurrence runs over the snippets of ONE video's DataLoader batch
+        (api/mimamo_net.py:119,139; api/tester.py:69-72), its batch dimension over the frames of a snippet.  GRU batch
+        elements are independent, so consecutive videos with the same snippet count S (<= batch_size) and snippet length
+        T share a call: their rows are laid out [s][video][t] and the call sees bs = S, T' = n_videos * T -- the same
+        bits as one call per video.  Independent 64-frame clips are the S = 1 case.  A video with more than batch_size
+        snippets is split into the reference's batches of batch_size snippets, each its own call."""
+        vids, groups = [], []
+        off, row0 = 0, 0
         for n in video_lengths:
             ranges = sampler.snippet_ranges(n, self.length, self.stride)
-            rows0 = sum(len(x) for x in ids)
-            for s, e in ranges:
-                ids.append(sampler.window_ids(s, e, n, self.num_phase) + off)
-            vids.append({"n": n, "offset": off, "ranges": ranges, "row0": rows0,
-                         "T": ranges[0][1] - ranges[0][0]})
+            T = ranges[0][1] - ranges[0][0]
+            vids.append({"n": n, "offset": off, "ranges": ranges, "row0": row0, "T": T})
             off += n
+            row0 += len(ranges) * T
+        cap_rows = max(self.batch_size * self.length, 1)
+        i = 0
+        while i < len(vids):
+            v = vids[i]
+            S, T = len(v["ranges"]), v["T"]
+            if S > self.batch_size:
+                for c0 in range(0, S, self.batch_size):
+                    c1 = min(S, c0 + self.batch_size)
+                    groups.append(self._group([v], c0, c1))
+                i += 1
+                continue
+            j, rows = i + 1, S * T
+            while (j < len(vids) and len(vids[j]["ranges"]) == S and vids[j]["T"] == T and rows + S * T <= cap_rows):
+                rows += S * T
+                j += 1
+            groups.append(self._group(vids[i:j], 0, S))
+            i = j
+        return {"videos": vids, "groups": groups, "n_frames": off, "n_rows": row0}
+
+    def _group(self, vs, c0, c1):
+        """Rows of snippets [c0, c1) of the videos `vs` in [s][video][t] order."""
+        T = vs[0]["T"]
+        ids, dest = [], []
+        for s in range(c0, c1):
+            for v in vs:
+                a, b = v["ranges"][s]
+                ids.append(sampler.window_ids(a, b, v["n"], self.num_phase) + v["offset"])
+                dest.append(np.arange(v["row0"] + s * T, v["row0"] + (s + 1) * T, dtype=np.int64))
         ids = np.concatenate(ids, axis=0)
-        # frame index (global) of every snippet row = centre column of its window
-        return {"videos": vids, "ids": torch.from_numpy(ids).to(self.device).contiguous(),
-                "rows": torch.from_numpy(ids[:, self.num_phase // 2].astype(np.int64)).to(self.device), "n_frames": off}
+        dest = np.concatenate(dest)
+        f0, f1 = int(ids.min()), int(ids.max()) + 1
+        rows = ids[:, self.num_phase // 2].astype(np.int64)      # frame of a row = centre column of its window
+        contiguous = bool((dest == np.arange(dest[0], dest[0] + len(dest))).all())
+        return {"bs": c1 - c0, "T": len(vs) * T, "f0": f0, "f1": f1,
+                "ids": torch.from_numpy(ids - f0).to(self.device).contiguous(),
+                "rows": None if (contiguous and bool((rows == np.arange(rows[0], rows[0] + len(rows))).all()))
+                else torch.from_numpy(rows).to(self.device),
+                "row_first": int(rows[0]),
+                "dest": None if contiguous else torch.from_numpy(dest).to(self.device),
+                "dest_first": int(dest[0]), "n": len(dest)}
 
     # ---- one pass of the hot path ------------------------------------------------------------------
     def forward(self, gray, rgb, plan, independent_clips=False):
         """gray [N,48,48] f32, rgb [N,3,224,224] f32 (or NHWC4) on the device, `plan` from plan().
         Returns [rows, 2] valence/arousal for every snippet row (snippet order).
 
-        independent_clips=True: every video is exactly one snippet of `length` frames, so each GRU call has
-        seq_len 1 and the calls are batched into one (identical results: GRU batch elements are independent)."""
-        J = plan["ids"].shape[0]
+        independent_clips=True asserts that every video is exactly one snippet (the bench's workload); the batching of
+        their GRU calls is what plan() does for any run of equal-shaped videos."""
+        self._check(plan, gray.shape[0], independent_clips)
+        feats = self.resnet.get_vec(rgb, channels_last4=(rgb.dim() == 4 and rgb.shape[-1] == 4))  # [N,2048], per unique frame
+        return self._rows(gray, feats, plan)
+
+    def forward_u8(self, frames_u8, plan, independent_clips=False):
+        """Same as forward() but from the raw boundary: uint8 aligned faces [N,112,112,3] on the device
+        (37.6 KB/frame over PCIe instead of 0.6 MB of fp32 tensors); PIL-exact preprocessing runs on the GPU,
+        chunk by chunk in front of the ResNet50 trunk so the fp32 RGB tensor never exists for more than one chunk."""
+        self._check(plan, frames_u8.shape[0], independent_clips)
+        if self._pre is None:
+            from .preprocess import FramePreprocessor
+            self._pre = FramePreprocessor(device=self.device)
+        N, step = frames_u8.shape[0], self.max_frames_per_call
+        if N <= step:
+            gray, rgb4 = self._pre(frames_u8, channels_last4=True)
+            feats = self.resnet.get_vec(rgb4, channels_last4=True)
+        else:
+            gray = torch.empty((N, self._pre.phase_size, self._pre.phase_size), dtype=torch.float32, device=frames_u8.device)
+            feats = torch.empty((N, 2048), dtype=torch.float32, device=frames_u8.device)
+            for c0 in range(0, N, step):
+                c1 = min(N, c0 + step)
+                g, rgb4 = self._pre(frames_u8[c0:c1], channels_last4=True)
+                gray[c0:c1] = g
+                self.resnet.get_vec(rgb4, channels_last4=True, out=feats[c0:c1])
+        return self._rows(gray, feats, plan)
+
+    def _check(self, plan, n_frames, independent_clips):
+        if n_frames != plan["n_frames"]:
+            raise ValueError("plan was built for %d frames, got %d" % (plan["n_frames"], n_frames))
         if independent_clips and any(len(v["ranges"]) != 1 for v in plan["videos"]):
             raise ValueError("independent_clips=True needs single-snippet videos: a multi-snippet video's GRU runs over "
-                             "its snippets (api/mimamo_net.py:119,139) and must get its own call")
-        p0, cat = self.pde.phase_diff_frames(gray, plan["ids"], nhwc=True, out1_cstride=88, out1_coffset=64)
-        feats = self.resnet.get_vec(rgb, channels_last4=(rgb.dim() == 4 and rgb.shape[-1] == 4))  # [N,2048], per unique frame
-        rgb_rows = feats if J == feats.shape[0] and independent_clips else feats.index_select(0, plan["rows"])
-        if independent_clips:
-            out = self.head.forward([p0, cat], rgb_rows.view(1, J, 2048), phase_layout="nhwc_cat")
-            return out.view(J, 2)
-        outs = []
-        for v in plan["videos"]:
-            T, S = v["T"], len(v["ranges"])
-            for c0 in range(0, S, self.batch_size):  # DataLoader(batch_size) chunks (api/tester.py:69-72)
-                c1 = min(S, c0 + self.batch_size)
-                r0, r1 = v["row0"] + c0 * T, v["row0"] + c1 * T
-                o = self.head.forward([p0[r0:r1], cat[r0:r1]], rgb_rows[r0:r1].view(c1 - c0, T, 2048),
-                                      phase_layout="nhwc_cat")
-                outs.append(o.view(-1, 2))
-        return torch.cat(outs, 0)
+                             "its snippets (api/mimamo_net.py:119,139)")
+
+    def _rows(self, gray, feats, plan):
+        groups = plan["groups"]
+        out = None
+        for g in groups:
+            p0, cat = self.pde.phase_diff_frames(gray[g["f0"]:g["f1"]], g["ids"], nhwc=True, out1_cstride=88, out1_coffset=64,
+                                                 ids_checked=True)
+            rgb_rows = (feats[g["row_first"]:g["row_first"] + g["n"]] if g["rows"] is None
+                        else feats.index_select(0, g["rows"]))
+            o = self.head.forward([p0, cat], rgb_rows.view(g["bs"], g["T"], 2048), phase_layout="nhwc_cat").view(-1, 2)
+            if len(groups) == 1 and g["dest"] is None:
+                return o
+            if out is None:
+                out = torch.empty((plan["n_rows"], 2), dtype=torch.float32, device=feats.device)
+            if g["dest"] is None:
+                out[g["dest_first"]:g["dest_first"] + g["n"]] = o
+            else:
+                out.index_copy_(0, g["dest"], o)
+        return out
 
     # ---- lanes: independent videos on several HIP streams ------------------------------------------------
     def forward_lanes(self, inputs, video_lengths, lanes=2, independent_clips=False, from_u8=False):
@@ -112,15 +194,6 @@ class HotPath(object):
         for st in streams:
             cur.wait_stream(st)
         return torch.cat(outs, 0)
-
-    def forward_u8(self, frames_u8, plan, independent_clips=False):
-        """Same as forward() but from the raw boundary: uint8 aligned faces [N,112,112,3] on the device
-        (37.6 KB/frame over PCIe instead of 0.6 MB of fp32 tensors); PIL-exact preprocessing runs on the GPU."""
-        if self._pre is None:
-            from .preprocess import FramePreprocessor
-            self._pre = FramePreprocessor(device=self.device)
-        gray, rgb4 = self._pre(frames_u8, channels_last4=True)
-        return self.forward(gray, rgb4, plan, independent_clips)
 
     def assemble(self, out_rows, plan, label_name=('valence', 'arousal')):
         """[rows,2] -> {video index: float64 [n_frames,2]} with the reference's overwrite order."""

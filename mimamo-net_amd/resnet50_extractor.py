@@ -17,17 +17,21 @@ from . import _lib, weights
 
 class Resnet50_Extractor(object):
     def __init__(self, benchmark_dir='pytorch-benchmarks', model_name='resnet50_ferplus_dag',
-                 feature_layer='pool5_7x7_s1', state_dict=None, device=None):
+                 feature_layer='pool5_7x7_s1', state_dict=None, device=None, max_frames_per_call=4096):
         """benchmark_dir/model_name/feature_layer as api/resnet50_extractor.py:14-15.
 
         state_dict: weights in the third-party key layout.  If None, `<benchmark_dir>/ferplus/<model_name>.pth`
         is loaded when it exists (the reference's location, api/resnet50_extractor.py:35-36); otherwise the
-        constructor asserts like the reference does (:33)."""
+        constructor asserts like the reference does (:33).
+        max_frames_per_call: get_vec runs the trunk over at most this many frames per launch sequence (17.3 MB of
+        activation workspace per frame), so memory does not grow with the batch the caller hands over; the reference
+        streams 64 frames at a time (:56-60)."""
         if feature_layer != 'pool5_7x7_s1':
             raise NotImplementedError("only the pool5_7x7_s1 hook of the reference is implemented")
         self.benchmark_dir = os.path.abspath(benchmark_dir)
         self.model_name = model_name
         self.feature_layer = feature_layer
+        self.max_frames_per_call = max(1, int(max_frames_per_call))
         if state_dict is None:
             assert os.path.exists(self.benchmark_dir), 'benchmark_dir must exits'
             pth = os.path.join(self.benchmark_dir, 'ferplus', model_name + '.pth')
@@ -72,22 +76,29 @@ class Resnet50_Extractor(object):
         self._ws[key] = ws
         return ws, need
 
-    def get_vec(self, image, channels_last4=False):
+    def get_vec(self, image, channels_last4=False, out=None):
         """image [bs,3,224,224] (255*x - mean) -> pool5 features [bs,2048] ON THE DEVICE.
 
         (api/resnet50_extractor.py:74-83 returns relu(squeeze()) of a CPU copy; squeeze() collapsing bs=1 and
-        the host copy are quirk Q8 and are not reproduced.)  channels_last4=True takes [bs,224,224,4]."""
+        the host copy are quirk Q8 and are not reproduced.)  channels_last4=True takes [bs,224,224,4].
+        out: optional preallocated [bs,2048] fp32 device tensor (contiguous rows) the features are written to."""
         if not image.is_cuda:
             raise RuntimeError("image must be on the ROCm device; this build has no CPU path")
         assert image.dtype == torch.float32
         bs = image.size(0)
         assert tuple(image.shape[1:]) == ((224, 224, 4) if channels_last4 else (3, 224, 224))
         image = image.contiguous()
-        out = torch.empty((bs, 2048), dtype=torch.float32, device=image.device)
-        ws, need = self._workspace(bs)
-        rc = _lib.lib().mm_resnet50_forward(self._handle, _lib.ptr(image), 0 if channels_last4 else 1, bs,
-                                            _lib.ptr(out), _lib.ptr(ws), need, _lib.current_stream())
-        _lib.check(rc, "mm_resnet50_forward")
+        if out is None:
+            out = torch.empty((bs, 2048), dtype=torch.float32, device=image.device)
+        else:
+            assert out.is_cuda and out.dtype == torch.float32 and tuple(out.shape) == (bs, 2048) and out.is_contiguous()
+        step = self.max_frames_per_call
+        ws, need = self._workspace(min(bs, step))
+        for c0 in range(0, bs, step):
+            c1 = min(bs, c0 + step)
+            rc = _lib.lib().mm_resnet50_forward(self._handle, _lib.ptr(image[c0:c1]), 0 if channels_last4 else 1, c1 - c0,
+                                                _lib.ptr(out[c0:c1]), _lib.ptr(ws), need, _lib.current_stream())
+            _lib.check(rc, "mm_resnet50_forward")
         return out
 
     def run(self, input_dir, output_dir, batch_size=64, video_name=''):

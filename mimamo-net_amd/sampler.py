@@ -106,6 +106,11 @@ def load_gray_batch(paths, phase_size=48):
             ow, oh = phase_size, int(phase_size * h / w)
         else:
             oh, ow = phase_size, int(phase_size * w / h)
+        if (ow, oh) != (phase_size, phase_size):
+            # the reference's `.view(len, 13, 48, 48)` (snippet_sampler.py:185) raises for non-square faces; a silent
+            # top-left crop would hand plausible but shifted phase images to the network instead
+            raise ValueError("aligned face %s is %dx%d: not square, cannot be viewed as %dx%d phase input"
+                             % (p, w, h, phase_size, phase_size))
         g = g.resize((ow, oh), Image.LANCZOS)
-        out[i] = np.asarray(g, dtype=np.float32)[:phase_size, :phase_size] / np.float32(255)
+        out[i] = np.asarray(g, dtype=np.float32) / np.float32(255)
     return torch.from_numpy(out)

@@ -74,9 +74,9 @@ TWO_STREAM_BN_KEYS = ("mlp.mlp.2", "mlp.mlp.6", "phasenet.conv_net.0.1", "phasen
                       "transform.2", "classifier.2")
 
 
-def make_two_stream_state_dict(seed=0, num_phase=12):
+def make_two_stream_state_dict(seed=0, num_phase=12, n_out=2):
     """Random-init state_dict with the exact key/shape layout of Two_Stream_RNN (107 tensors
-    incl. the 13 `num_batches_tracked` counters)."""
+    incl. the 13 `num_batches_tracked` counters).  n_out = len(label_name.split('_'))."""
     sd = {}
     _lin(sd, "mlp.mlp.1", 256, 2048, seed)
     _bn(sd, "mlp.mlp.2", 256, seed)
@@ -105,8 +105,8 @@ def make_two_stream_state_dict(seed=0, num_phase=12):
                               ("bias_ih", (384,)), ("bias_hh", (384,))):
                 key = "rnns.%s_l%d%s" % (nm, l, sfx)
                 sd[key] = det_uniform(key, shape, -k, k, seed)
-    _lin(sd, "classifier.1", 2, 256, seed)
-    _bn(sd, "classifier.2", 2, seed)
+    _lin(sd, "classifier.1", n_out, 256, seed)
+    _bn(sd, "classifier.2", n_out, seed)
     for bn in TWO_STREAM_BN_KEYS:
         sd[bn + ".num_batches_tracked"] = np.zeros((), dtype=np.int64)
     return sd
@@ -136,14 +136,16 @@ def resnet50_layers(stride_on_first_1x1=True):
     return layers
 
 
-def make_resnet50_state_dict(seed=0):
+def make_resnet50_state_dict(seed=0, gamma_mid=(0.8, 1.2), gamma_out=(0.35, 0.55)):
     """Random-init ResNet-50 trunk (He-scaled convs; BN gamma~1, beta~0, var~1; the last BN
-    of every bottleneck is damped so 16 residual adds keep activations O(1..10))."""
+    of every bottleneck is damped so 16 residual adds keep activations O(1..10)).
+    gamma_mid / gamma_out: BN weight ranges of the reduce + 3x3 layers / of the increase + projection layers; the
+    numerical stress tests widen them (per-channel dynamic range, activations of 1e3 and beyond)."""
     sd = {}
     for name, cin, cout, k, _, _ in resnet50_layers():
         _conv(sd, name, cout, cin, k, seed, bias=False)
-        damp = name.endswith("1x1_increase") or name.endswith("1x1_proj")
-        _bn(sd, name + "_bn", cout, seed, gamma=(0.35, 0.55) if damp else (0.8, 1.2))
+        out = name.endswith("1x1_increase") or name.endswith("1x1_proj")
+        _bn(sd, name + "_bn", cout, seed, gamma=gamma_out if out else gamma_mid)
     return sd
 
 
@@ -180,6 +182,22 @@ def two_stream_float_keys():
     if TWO_STREAM_FLOAT_KEYS is None:
         TWO_STREAM_FLOAT_KEYS = [k for k in make_two_stream_state_dict(0) if not k.endswith("num_batches_tracked")]
     return TWO_STREAM_FLOAT_KEYS
+
+
+def widen_classifier(state_dict):
+    """A one-output head (label_name 'arousal' or 'valence': Linear(256,1) + BatchNorm1d(1), api/mimamo_net.py:120-122)
+    in the library's two-output layout: output 0 is the checkpoint's, output 1 an inert row (zero weights, identity BN)
+    that the caller slices away.  Output channels of the classifier GEMM are independent, so column 0 is unchanged."""
+    sd = dict(state_dict)
+    z = lambda v, fill: np.concatenate([_np(v).reshape((1,) + tuple(np.shape(v))[1:]),                     # noqa: E731
+                                        np.full((1,) + tuple(np.shape(v))[1:], fill, dtype=np.float32)])
+    sd["classifier.1.weight"] = z(state_dict["classifier.1.weight"], 0.0)
+    sd["classifier.1.bias"] = z(state_dict["classifier.1.bias"], 0.0)
+    sd["classifier.2.weight"] = z(state_dict["classifier.2.weight"], 1.0)
+    sd["classifier.2.bias"] = z(state_dict["classifier.2.bias"], 0.0)
+    sd["classifier.2.running_mean"] = z(state_dict["classifier.2.running_mean"], 0.0)
+    sd["classifier.2.running_var"] = z(state_dict["classifier.2.running_var"], 1.0)
+    return sd
 
 
 def two_stream_blob(state_dict):

@@ -1,0 +1,57 @@
+"""bench.py through its driver-facing entry point on the GPU box: `--gpus N` really starts N ranks (two ranks share the
+single GPU of the test box, so the process group is gloo there; RCCL is exercised with a one-rank group), the work queue is
+broadcast and sharded, and the sharded job computes the same rows as a single rank."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _bench(*args, timeout=900):
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + [str(a) for a in args], env=env, stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, universal_newlines=True, timeout=timeout)
+    assert r.returncode == 0, r.stderr[-3000:]
+    return json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+
+
+def test_two_ranks_compute_the_same_rows_as_one(tmp_path):
+    common = ("--steps", 2, "--warmup", 1, "--total-clips", 4, "--no-cpu-baseline", "--no-extra", "--lanes", 1)
+    d2 = _bench("--gpus", 2, "--same-device", "--backend", "gloo", "--clips", 2, "--dump-out", tmp_path / "two.npy", *common)
+    d1 = _bench("--gpus", 1, "--clips", 4, "--dump-out", tmp_path / "one.npy", *common)
+    assert d2["n_gpus"] == 2 and d1["n_gpus"] == 1
+    assert d2["config"]["work_queue"]["broadcast"] == "gloo" and d2["config"]["work_queue"]["clips_this_rank"] == 2
+    assert d2["value"] > 0 and d2["roofline"]["frac"] > 0
+    two, one = np.load(tmp_path / "two.npy"), np.load(tmp_path / "one.npy")
+    assert two.shape == one.shape == (256, 2) and np.isfinite(one).all()
+    # rank 0 holds clips 0, 2 and rank 1 clips 1, 3 (dist.shard: c mod world == rank); gathered rank-major
+    order = [0, 2, 1, 3]
+    for pos, clip in enumerate(order):
+        np.testing.assert_array_equal(two[pos * 64:(pos + 1) * 64], one[clip * 64:(clip + 1) * 64])
+
+
+def test_one_rank_process_group_over_rccl():
+    """The broadcast / all-gather / barrier / max-reduce path on RCCL itself (a one-rank group is all a 1-GPU box allows)."""
+    d = _bench("--gpus", 1, "--force-dist", "--steps", 2, "--warmup", 1, "--clips", 2, "--no-cpu-baseline", "--no-extra")
+    assert d["n_gpus"] == 1 and d["config"]["work_queue"]["broadcast"] == "nccl" and d["value"] > 0
+
+
+def test_default_line_has_the_contract_fields():
+    d = _bench("--steps", 2, "--warmup", 1, "--clips", 4, "--cpu-clips", 1, "--extra-steps", 1)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert "uint8" in d["config"]["workload"] and d["dtype"] == "f32" and d["vs_baseline"] is None
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in d["roofline"], k
+    cb = d["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["cpu_model"] and cb["deduplicated"]["value"] > 0
+    ex = d["extra"]
+    assert ex["direct_form"]["value"] > 0 and ex["multi_snippet"]["gru_seq_len"] == 5 and ex["multi_snippet"]["value"] > 0
+    assert d["parity_vs_cpu_sample"]["max_abs_err_valence_arousal"] < 1e-4

@@ -122,3 +122,23 @@ def test_scfpyr_config_errors(L):
     assert q(96, 4, 2, 2) == 0 and side.value == 96 and cp.value == 0
     h = ctypes.c_void_p()
     assert L.mm_scfpyr_create(ctypes.byref(h), 96, 4, 2, 2) == -5  # no device here: fails loudly
+
+
+def test_weight_blobs_accept_checkpoint_files_as_stored(pkg):
+    """torch tensors, BN `num_batches_tracked` counters and the third-party model's unused `classifier.*` keys do not
+    change the blobs handed to mm_resnet50_create / mm_head_create (api/utils/model_utils.py:65-79, api/tester.py:47-49)."""
+    import torch
+    from mimamo_net_amd import weights
+    rs = weights.make_resnet50_state_dict(seed=1)
+    disk = {k: torch.from_numpy(np.asarray(v)) for k, v in rs.items()}
+    disk["classifier.weight"] = torch.zeros(8, 2048, 1, 1)
+    disk["classifier.bias"] = torch.zeros(8)
+    disk["conv1_7x7_s2_bn.num_batches_tracked"] = torch.tensor(3)
+    np.testing.assert_array_equal(weights.resnet50_blob(disk), weights.resnet50_blob(rs))
+    hs = weights.make_two_stream_state_dict(seed=1)
+    np.testing.assert_array_equal(weights.two_stream_blob({k: torch.from_numpy(np.asarray(v)) for k, v in hs.items()}),
+                                  weights.two_stream_blob(hs))
+    one = weights.make_two_stream_state_dict(seed=1, n_out=1)
+    wide = weights.widen_classifier(one)
+    assert wide["classifier.1.weight"].shape == (2, 256) and (wide["classifier.1.weight"][1] == 0).all()
+    assert weights.two_stream_blob(wide).size == weights.two_stream_blob(hs).size

@@ -108,3 +108,57 @@ def test_two_process_gloo_shard_and_gather():
         p.join(timeout=60)
         assert p.exitcode == 0
     assert all(ok for _, ok, _ in got) and all(keys == [0, 1, 2, 3, 4] for _, _, keys in got)
+
+
+# ---- bench.py launcher / work queue (the driver-facing multi-GPU entry point), with a stub compute on CPU ranks --------
+def _run_bench(*args, env=None, timeout=240):
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    e = dict(os.environ if env is None else env)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        if env is None:
+            e.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + [str(a) for a in args], env=e, stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, universal_newlines=True, timeout=timeout)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    return r, (json.loads(lines[-1]) if lines else None)
+
+
+def test_bench_gpus_flag_spawns_that_many_ranks(tmp_path):
+    """`bench.py --gpus 2` without a torchrun environment starts two ranks itself (gloo here), broadcasts the work queue
+    from rank 0, shards it round-robin and all-gathers the rows: one JSON line with n_gpus == 2."""
+    dump = str(tmp_path / "rows.npy")
+    r, d = _run_bench("--gpus", 2, "--stub-compute", "--steps", 3, "--warmup", 1, "--clips", 2, "--total-clips", 10,
+                      "--distinct-clips", 10, "--dump-out", dump)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["scaling"] == "weak" and d["value"] > 0
+    q = d["config"]["work_queue"]
+    assert q["total_clips"] == 10 and q["clips_this_rank"] == 5 and q["broadcast"] == "gloo"
+    rows = np.load(dump)                       # last step (index 3 incl. warm-up): rank 0 holds clips 0,2,4,6,8; rank 1 the odd ones
+    assert rows.shape == (2 * 2 * 64, 2)
+    # step s takes shard positions 2s, 2s+1 (wrapping): s = 3 -> positions 6,7 -> 1,2 -> clips 2,4 (rank 0), 3,5 (rank 1)
+    assert list(rows[::64, 0]) == [2, 4, 3, 5] and (rows[:64, 1] == np.arange(64)).all()
+
+
+def test_bench_gpus_flag_must_match_launcher_world_size():
+    r, d = _run_bench("--gpus", 4, "--stub-compute", env=dict(os.environ, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0"))
+    assert r.returncode != 0 and d is None and "does not match WORLD_SIZE" in r.stderr
+
+
+def test_bench_whole_job_walks_the_queue_once_with_a_ragged_tail(tmp_path):
+    dump = str(tmp_path / "rows.npy")
+    r, d = _run_bench("--gpus", 3, "--stub-compute", "--whole-job", "--total-clips", 11, "--clips", 2, "--distinct-clips", 11,
+                      "--dump-out", dump)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert d["n_gpus"] == 3 and d["steps"] == 2 and d["scaling"] == "strong"
+    rows = np.load(dump)[::64, 0]              # last step: rank 0 -> 6, 9; rank 1 -> 7, 10; rank 2 -> 8 and one empty slot
+    assert list(rows[:5]) == [6, 9, 7, 10, 8] and np.isnan(rows[5])
+
+
+def test_bench_refuses_to_run_without_a_gpu():
+    if torch.cuda.is_available():
+        pytest.skip("GPU host")
+    r, d = _run_bench("--steps", 1, "--no-cpu-baseline")
+    assert r.returncode != 0 and d is None and "no CPU path" in r.stderr

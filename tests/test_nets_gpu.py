@@ -1,13 +1,14 @@
 """GPU parity: fp32 MFMA conv engine, two-stream head and ResNet50 pool5 (through the C ABI) vs the oracle
 (torch fp32 CPU restatement) and the golden head outputs frozen from the real reference."""
 import ctypes
+import os
 
 import numpy as np
 import pytest
 import torch
 import torch.nn.functional as F
 
-from mimamo_net_amd import weights
+from mimamo_net_amd import synthetic, weights
 
 pytestmark = pytest.mark.gpu
 
@@ -292,3 +293,110 @@ def test_zero_sized_calls_are_noops(pkg, dev):
     m = Two_Stream_RNN().load_state_dict(weights.make_two_stream_state_dict(seed=3)).eval().to(dev)
     y = m([torch.zeros(0, 4, 24, 48, 48, device=dev), torch.zeros(0, 4, 24, 24, 24, device=dev)], torch.zeros(0, 4, 2048, device=dev))
     assert tuple(y.shape) == (0, 4, 2)
+
+
+@pytest.mark.parametrize("label_name", ["arousal", "valence"])
+def test_head_single_label_variants(oracle, dev, label_name):
+    """Two_Stream_RNN(label_name='arousal'|'valence'): Linear(256,1) + BatchNorm1d(1) output layer
+    (api/mimamo_net.py:97-122), checkpoints of torch tensors incl. the BN counters."""
+    from mimamo_net_amd.mimamo_net import Two_Stream_RNN
+    sd = weights.make_two_stream_state_dict(seed=5, n_out=1)
+    m = Two_Stream_RNN(label_name=label_name)
+    m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()})
+    m.eval().to(dev)
+    p0, p1, rgb = _head_inputs(2, 16, 91)
+    y = m([torch.from_numpy(p0).to(dev), torch.from_numpy(p1).to(dev)], torch.from_numpy(rgb).to(dev))
+    assert tuple(y.shape) == (2, 16, 1)
+    want = oracle.two_stream_forward(sd, p0, p1, rgb)
+    assert want.shape == (2, 16, 1) and np.abs(y.cpu().numpy() - want).max() < 2e-5
+    with pytest.raises(RuntimeError, match="size mismatch"):
+        Two_Stream_RNN(label_name=label_name).load_state_dict(weights.make_two_stream_state_dict(seed=5))
+    with pytest.raises(ValueError):
+        Two_Stream_RNN(label_name="dominance")
+
+
+def test_checkpoints_in_the_third_party_layout_load_from_disk(oracle, dev, tmp_path):
+    """The day the real files exist they must just load: `<benchmark_dir>/ferplus/resnet50_ferplus_dag.pth` as the
+    third-party model file stores it (torch tensors, the unused `classifier.*` 1x1 conv of the FER+ head, BatchNorm
+    `num_batches_tracked` counters; api/utils/model_utils.py:65-79, api/resnet50_extractor.py:36-41) and
+    `model_weights.pth.tar` = {'epoch', 'state_dict'} (api/tester.py:47-49)."""
+    from mimamo_net_amd.resnet50_extractor import Resnet50_Extractor
+    from mimamo_net_amd.tester import Tester
+    rs = weights.make_resnet50_state_dict(seed=2)
+    on_disk = {k: torch.from_numpy(np.asarray(v)) for k, v in rs.items()}
+    for k in list(on_disk):
+        if k.endswith("_bn.running_var"):
+            on_disk[k[:-len("running_var")] + "num_batches_tracked"] = torch.tensor(12345, dtype=torch.int64)
+    on_disk["classifier.weight"] = torch.zeros(8, 2048, 1, 1)
+    on_disk["classifier.bias"] = torch.zeros(8)
+    bdir = tmp_path / "pytorch-benchmarks"
+    os.makedirs(bdir / "ferplus")
+    torch.save(on_disk, str(bdir / "ferplus" / "resnet50_ferplus_dag.pth"))
+    ext = Resnet50_Extractor(benchmark_dir=str(bdir), model_name="resnet50_ferplus_dag", feature_layer="pool5_7x7_s1")
+    x = weights.det_uniform("ckpt.x", (2, 3, 224, 224), -120.0, 120.0, 4)
+    got = ext.get_vec(torch.from_numpy(x).to(dev)).cpu().numpy()
+    want = oracle.resnet50_pool5(rs, x)
+    assert np.abs(got - want).max() / np.abs(want).max() < 1e-4
+    with pytest.raises(AssertionError):
+        Resnet50_Extractor(benchmark_dir=str(tmp_path / "nowhere"))
+    head_sd = {k: torch.from_numpy(np.asarray(v)) for k, v in weights.make_two_stream_state_dict(seed=2).items()}
+    torch.save({"epoch": 7, "state_dict": head_sd}, str(tmp_path / "model_weights.pth.tar"))
+    t = Tester(str(tmp_path / "model_weights.pth.tar"), batch_size=64, workers=8, quiet=True, benchmark_dir=str(bdir))
+    res = t.test_frames([synthetic.make_clip_u8(3, 20)], names=["v"])
+    assert res["v"].shape == (20, 2) and np.isfinite(res["v"].values).all()
+
+
+WINO_STRESS = {
+    # BN gamma of reduce/3x3 in [0.5, 4] (8x per-channel dynamic range into every 3x3 layer), weakly damped increase
+    # layers: activations of 1e3 .. 1e4 inside the blocks, pool5 ~ 1e3
+    "wide_gamma": dict(gamma_mid=(0.5, 4.0), gamma_out=(0.05, 0.15)),
+    # no damping at all: every BN gamma ~ 1, the 16 residual adds grow the activations to ~ 1e5 .. 1e6
+    "undamped": dict(gamma_mid=(0.8, 1.2), gamma_out=(0.8, 1.2)),
+}
+
+
+@pytest.mark.parametrize("case", sorted(WINO_STRESS))
+def test_winograd_error_where_it_can_hurt(oracle, dev, case):
+    """Winograd F(4x4,3x3) / F(2x2,3x3) / direct form against a float64 evaluation of the same graph, on weights and
+    inputs chosen to expose the transforms' larger constants: wide per-channel BN scales, activations of 1e3 and beyond,
+    inputs at the extremes of the uint8 range (0 / 255 checkerboard noise minus the mean).  Reported per mode: pool5
+    max / mean error relative to the largest feature, and the end-to-end valence/arousal error after the two-stream head
+    (north_star: within 1e-4).  The fp32 CPU oracle (the reference's arithmetic: direct fp32 convs) is measured against
+    the same float64 truth for scale."""
+    from mimamo_net_amd.mimamo_net import Two_Stream_RNN
+    from mimamo_net_amd.resnet50_extractor import Resnet50_Extractor
+    rs = weights.make_resnet50_state_dict(seed=7, **WINO_STRESS[case])
+    n = 8
+    sel = weights.det_uniform("stress.sel", (n, 3, 224, 224), 0.0, 1.0, 2) < 0.5
+    mean = np.asarray(weights.RESNET50_MEAN, dtype=np.float32)[None, :, None, None]
+    x = (np.where(sel, np.float32(0.0), np.float32(255.0)) - mean).astype(np.float32)       # 255*x - mean at x in {0, 1}
+    truth = oracle.resnet50_pool5(rs, x, dtype=np.float64)
+    scale = np.abs(truth).max()
+    cpu32 = oracle.resnet50_pool5(rs, x)
+    ext = Resnet50_Extractor(state_dict=rs, device=dev)
+    head_sd = weights.make_two_stream_state_dict(seed=3)
+    # scale-free head check: features normalised to O(1) so 1e-4 absolute is meaningful whatever the trunk's gain
+    gain = np.float32(1.0 / max(1.0, float(truth.mean())))
+    p0, p1, _ = _head_inputs(1, n, 17)
+    want_out = oracle.two_stream_forward(head_sd, p0.astype(np.float64), p1.astype(np.float64),
+                                         (truth * gain)[None], dtype=np.float64)
+    head = Two_Stream_RNN().load_state_dict(head_sd).eval().to(dev)
+    tp0, tp1 = torch.from_numpy(p0).to(dev), torch.from_numpy(p1).to(dev)
+    xt = torch.from_numpy(x).to(dev)
+    rows = {"cpu fp32 (reference arithmetic)": cpu32}
+    for mode in (4, 2, 0):
+        ext.set_winograd(mode)
+        rows["hip winograd %d" % mode] = ext.get_vec(xt).cpu().numpy()
+    worst = {}
+    print("\n[%s] pool5 |truth| max %.3e mean %.3e" % (case, scale, truth.mean()))
+    for name, got in rows.items():
+        e = np.abs(got.astype(np.float64) - truth) / scale
+        feats = torch.from_numpy((got * gain).astype(np.float32)).to(dev)[None]
+        out = head([tp0, tp1], feats).cpu().numpy().astype(np.float64)
+        oe = np.abs(out - want_out).max()
+        worst[name] = (e.max(), e.mean(), oe)
+        print("  %-32s pool5 max rel %.2e mean rel %.2e | valence/arousal max abs err %.2e" % (name, e.max(), e.mean(), oe))
+    d, w4, w2 = worst["hip winograd 0"], worst["hip winograd 4"], worst["hip winograd 2"]
+    assert d[0] < 1e-4 and d[1] < 1e-5 and d[2] < OUT_ATOL, d                  # the direct form holds the stated bounds
+    assert w2[0] < 1e-4 and w2[1] < 1e-5 and w2[2] < OUT_ATOL, w2
+    assert w4[0] < 1e-4 and w4[1] < 1e-5 and w4[2] < OUT_ATOL, w4              # F(4x4,3x3) stays the default only if it does too

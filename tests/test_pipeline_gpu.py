@@ -184,3 +184,68 @@ def test_reference_style_dataloader_loop_matches_fused_path(tester, oracle):
     assert res["v"].shape == (n, 2)
     # same kernels; only the pyramid de-duplication differs, which is exact per frame
     np.testing.assert_array_equal(res["v"].values, fused["v"].values)
+
+
+def test_equal_shaped_videos_share_one_gru_call_and_match_per_video_calls(tester):
+    """plan() lays consecutive videos with the same snippet count out as [snippet][video][frame] and runs ONE head call
+    (GRU seq_len = snippets, batch = videos x frames): same bits as one call per video, because GRU batch elements are
+    independent (api/mimamo_net.py:119,139) -- and never merges videos of different snippet counts."""
+    hot, dev = tester.hot, tester.device
+    lengths = [150, 150, 150, 64, 64, 200]
+    plan = hot.plan(lengths)
+    assert [(g["bs"], g["T"]) for g in plan["groups"]] == [(3, 3 * 64), (1, 2 * 64), (4, 64)]
+    g = torch.Generator(device="cpu").manual_seed(11)
+    n = sum(lengths)
+    gray = torch.rand(n, 48, 48, generator=g).to(dev)
+    rgb = (torch.rand(n, 224, 224, 4, generator=g) * 200 - 100).to(dev)
+    rgb[..., 3] = 0
+    with torch.no_grad():
+        res = hot.assemble(hot.forward(gray, rgb, plan), plan)
+        off = 0
+        for i, L in enumerate(lengths):
+            p1 = hot.plan([L])
+            assert len(p1["groups"]) == 1
+            alone = hot.assemble(hot.forward(gray[off:off + L].contiguous(), rgb[off:off + L].contiguous(), p1), p1)[0]
+            np.testing.assert_array_equal(res[i], alone)
+            off += L
+
+
+def test_long_videos_stream_through_bounded_chunks(pkg, oracle):
+    """A video longer than batch_size snippets is split into the reference's DataLoader batches (api/tester.py:69-72), each
+    its own GRU call; preprocessing + ResNet50 run max_frames_per_call frames at a time.  Same values as the oracle run
+    with the same batch size, and as an un-chunked pass."""
+    from mimamo_net_amd.pipeline import HotPath
+    head_sd, rs_sd = weights.make_two_stream_state_dict(seed=0), weights.make_resnet50_state_dict(seed=0)
+    small = HotPath(head_sd, rs_sd, "cuda:0", length=8, stride=8, batch_size=2, max_frames_per_call=7)
+    big = HotPath(head_sd, rs_sd, "cuda:0", length=8, stride=8, batch_size=2)
+    n = 37                                           # 5 snippets (tail [29,37)) -> batches of 2, 2, 1 snippets
+    clip = synthetic.make_clip_u8(90, n)
+    plan = small.plan([n])
+    assert [(g["bs"], g["T"]) for g in plan["groups"]] == [(2, 8), (2, 8), (1, 8)]
+    frames = torch.from_numpy(clip).to("cuda:0")
+    with torch.no_grad():
+        a = small.assemble(small.forward_u8(frames, plan), plan)[0]
+        b = big.assemble(big.forward_u8(frames, big.plan([n])), plan)[0]
+    np.testing.assert_array_equal(a, b)
+    # oracle with the reference's semantics at the same snippet length / batch size
+    gray, rgb = synthetic.preprocess_host(clip)
+    ranges = oracle.snippet_ranges(n, 8, 8)
+    feats = oracle.resnet50_pool5(rs_sd, rgb)
+    ph = np.stack([gray[oracle.window_ids(s, e, n)] for s, e in ranges])
+    rg = np.stack([feats[s:e] for s, e in ranges])
+    preds = []
+    for c0 in range(0, len(ranges), 2):
+        p0, p1 = oracle.phase_diff_output(ph[c0:c0 + 2])
+        preds.extend(list(oracle.two_stream_forward(head_sd, p0, p1, rg[c0:c0 + 2])))
+    want = oracle.assemble(preds, ranges)
+    assert np.abs(a - want).max() < OUT_ATOL
+
+
+def test_plan_and_window_ids_are_validated(tester):
+    hot, dev = tester.hot, tester.device
+    plan = hot.plan([64])
+    with pytest.raises(ValueError, match="plan was built for 64 frames"):
+        hot.forward(torch.zeros(32, 48, 48, device=dev), torch.zeros(32, 224, 224, 4, device=dev), plan)
+    ids = torch.from_numpy(sampler.window_ids(0, 64, 64)).to(dev)
+    with pytest.raises(ValueError, match="window_ids must index"):
+        tester.phase_difference_extractor.phase_diff_frames(torch.rand(32, 48, 48, device=dev), ids)

@@ -28,7 +28,7 @@ with torch.no_grad():
         n = clips * 64
         gray = torch.rand(n, 48, 48, device=dev)
         plan = hot.plan([64] * clips)
-        dt = timeit(lambda: hot.pde.phase_diff_frames(gray, plan["ids"], nhwc=True, out1_cstride=88, out1_coffset=64), 20)
+        dt = timeit(lambda: hot.pde.phase_diff_frames(gray, plan["groups"][0]["ids"], nhwc=True, out1_cstride=88, out1_coffset=64), 20)
         print("   %4d clips (%6d frames): %.3f ms  %.2f M frames/s  %.0f GB/s algorithmic" % (clips, n, dt * 1e3, n / dt / 1e6, n * 285696 / dt / 1e9))
     print("configs[2]  ResNet50 pool5 extractor (fp32 NCHW batches resident in HBM)")
     for bs in (64, 256, 1024):
