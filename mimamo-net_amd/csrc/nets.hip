@@ -9,6 +9,7 @@
 // Eval-mode BatchNorm is folded into the preceding conv/linear on the host (float64) when it directly follows it;
 // BatchNorm placed after a ReLU (PhaseNet.fc, transform) runs as the conv engine's post-ReLU affine.
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include "conv.h"
@@ -147,12 +148,21 @@ static int run_layer(const Layer& L, const float* in, int B, int H, int W, int i
 
 // Stride-1 3x3 layer through Winograd F(2x2,3x3): input transform, ONE batched GEMM launch (16 problems), output
 // transform with the fused bias/ReLU.  V and M are caller-provided scratch of 16*B*ceil(H/2)*ceil(W/2)*C floats.
+static int g_wino_fused_shape = 0;   // measurement knob (MM_WINO_FUSED_SHAPE): workgroup shape of the fused kernel, 0 = auto
+
 static int run_layer_wino(const Layer& L, const float* in, int B, int H, int W, float* out, float* V, float* M, int m, hipStream_t s) {
-    const int TH = (H + m - 1) / m, TW = (W + m - 1) / m, npos = (m + 2) * (m + 2);
+    const int mt = m == 5 ? 4 : m;
+    const int TH = (H + mt - 1) / mt, TW = (W + mt - 1) / mt, npos = (mt + 2) * (mt + 2);
     const int64_t ntile = (int64_t)B * TH * TW;
     if (ntile > 0x7fffffff) return MM_ERR_INVALID_ARG;
+    const bool fused = m == 5;          // F(4x4,3x3) with the output transform inside the GEMM kernel (wino_fused.hip)
+    if (fused) m = 4;
     int rc = wino_input_transform(in, V, B, H, W, L.cin, m, s);
     if (rc != MM_OK) return rc;
+    if (fused) {
+        rc = wino_gemm_output_fused(V, L.wino_u4, L.bias, out, B, H, W, L.cin, L.cout, L.relu, g_wino_fused_shape, s);
+        if (rc != MM_ERR_UNSUPPORTED) return rc;
+    }
     ConvParams p;
     std::memset(&p, 0, sizeof(p));
     p.in = V; p.w = m == 4 ? L.wino_u4 : L.wino_u; p.out = M;
@@ -328,8 +338,10 @@ int64_t mm_resnet50_workspace_bytes(mm_resnet50_t* h, int64_t batch) {
 
 int mm_resnet50_set_winograd(mm_resnet50_t* h, int enable) {
     if (!h) return MM_ERR_INVALID_ARG;
-    if (enable != 0 && enable != 1 && enable != 2 && enable != 4) return MM_ERR_INVALID_ARG;
+    if (enable != 0 && enable != 1 && enable != 2 && enable != 4 && enable != 5) return MM_ERR_INVALID_ARG;
     h->winograd = enable == 1 ? 4 : enable;   // 1 = default variant
+    const char* sh = getenv("MM_WINO_FUSED_SHAPE");
+    mm::g_wino_fused_shape = sh ? atoi(sh) : 0;
     return MM_OK;
 }
 
@@ -388,8 +400,9 @@ int mm_resnet50_forward(mm_resnet50_t* h, const float* images, int nchw, int64_t
         rc = run_layer(Bk.reduce, x, B, H, W, C, 0, y1, Bk.reduce.cout, 0, nullptr, 0, s, &H1, &W1);
         if (rc != MM_OK) return rc;
         const int wm_ = h->winograd;
+        const int wt_ = wm_ == 5 ? 4 : wm_;   // tile side of the variant
         if (wm_ && Bk.conv3.wino_u &&
-            (int64_t)(wm_ + 2) * (wm_ + 2) * ((H1 + wm_ - 1) / wm_) * ((W1 + wm_ - 1) / wm_) * Bk.conv3.cin <= kRsWino) {
+            (int64_t)(wt_ + 2) * (wt_ + 2) * ((H1 + wt_ - 1) / wt_) * ((W1 + wt_ - 1) / wt_) * Bk.conv3.cin <= kRsWino) {
             rc = run_layer_wino(Bk.conv3, y1, B, H1, W1, y2, wv, wm, wm_, s);
             H2 = H1; W2 = W1;
         } else {

@@ -49,7 +49,9 @@ class Resnet50_Extractor(object):
 
     def set_winograd(self, mode=True):
         """Algorithm of the stride-1 3x3 layers of conv2_x..conv5_x: True/1 = default (Winograd F(4x4,3x3)),
-        2 = F(2x2,3x3), 4 = F(4x4,3x3), False/0 = direct implicit GEMM."""
+        2 = F(2x2,3x3), 4 = F(4x4,3x3) as three kernels (input transform, 36 batched GEMMs, output transform),
+        5 = F(4x4,3x3) with the output transform fused into the position GEMMs (csrc/wino_fused.hip),
+        False/0 = direct implicit GEMM."""
         mode = {True: 1, False: 0}.get(mode, mode)
         _lib.check(_lib.lib().mm_resnet50_set_winograd(self._handle, int(mode)), "mm_resnet50_set_winograd")
 

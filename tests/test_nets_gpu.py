@@ -261,7 +261,7 @@ def test_resnet50_winograd_and_direct_paths_agree(resnet, oracle, dev):
     scale = np.abs(want).max()
     got = {}
     try:
-        for mode in (4, 2, 0):
+        for mode in (5, 4, 2, 0):      # 5 = F(4x4,3x3) with the output transform fused into the position GEMMs
             resnet.set_winograd(mode)
             got[mode] = resnet.get_vec(xt).cpu().numpy()
     finally:
@@ -384,7 +384,7 @@ def test_winograd_error_where_it_can_hurt(oracle, dev, case):
     tp0, tp1 = torch.from_numpy(p0).to(dev), torch.from_numpy(p1).to(dev)
     xt = torch.from_numpy(x).to(dev)
     rows = {"cpu fp32 (reference arithmetic)": cpu32}
-    for mode in (4, 2, 0):
+    for mode in (5, 4, 2, 0):
         ext.set_winograd(mode)
         rows["hip winograd %d" % mode] = ext.get_vec(xt).cpu().numpy()
     worst = {}
@@ -396,7 +396,8 @@ def test_winograd_error_where_it_can_hurt(oracle, dev, case):
         oe = np.abs(out - want_out).max()
         worst[name] = (e.max(), e.mean(), oe)
         print("  %-32s pool5 max rel %.2e mean rel %.2e | valence/arousal max abs err %.2e" % (name, e.max(), e.mean(), oe))
-    d, w4, w2 = worst["hip winograd 0"], worst["hip winograd 4"], worst["hip winograd 2"]
+    d, w4, w2, w5 = worst["hip winograd 0"], worst["hip winograd 4"], worst["hip winograd 2"], worst["hip winograd 5"]
+    assert w5[0] < 1e-4 and w5[1] < 1e-5 and w5[2] < OUT_ATOL, w5
     assert d[0] < 1e-4 and d[1] < 1e-5 and d[2] < OUT_ATOL, d                  # the direct form holds the stated bounds
     assert w2[0] < 1e-4 and w2[1] < 1e-5 and w2[2] < OUT_ATOL, w2
     assert w4[0] < 1e-4 and w4[1] < 1e-5 and w4[2] < OUT_ATOL, w4              # F(4x4,3x3) stays the default only if it does too
