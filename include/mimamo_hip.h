@@ -179,9 +179,11 @@ int64_t mm_resnet50_blob_floats(void);
 int mm_resnet50_create(mm_resnet50_t** out, const float* host_blob, int64_t n_floats,
                        int stride_on_first_1x1, int maxpool_ceil_mode, float bn_eps);
 int mm_resnet50_destroy(mm_resnet50_t* h);
-/* The stride-1 3x3 layers of conv3_x..conv5_x run by default as Winograd F(4x4,3x3) (4x fewer multiply-adds, same
- * result up to fp32 rounding).  mode: 0 = every layer in the direct implicit-GEMM form, 2 = F(2x2,3x3), 4 = F(4x4,3x3),
- * 1 = the default variant. */
+/* The stride-1 3x3 layers of conv2_x..conv5_x (16 layers) run by default as Winograd F(4x4,3x3) (4x fewer multiply-adds,
+ * same result up to fp32 rounding).  mode: 0 = every layer in the direct implicit-GEMM form, 2 = F(2x2,3x3) as three kernels
+ * (input transform, batched position GEMMs, output transform), 4 = F(4x4,3x3) as three kernels, 5 = F(4x4,3x3) with the output
+ * transform fused into the position GEMMs (csrc/wino_fused.hip: the M planes never reach HBM), 1 = the default: variant 5 for
+ * the layers with <= 128 input channels (conv2_x, conv3_x), variant 4 for the others. */
 int mm_resnet50_set_winograd(mm_resnet50_t* h, int enable);
 int64_t mm_resnet50_workspace_bytes(mm_resnet50_t* h, int64_t batch);
 /* images: device f32, [batch,3,224,224] (nchw=1, the reference's layout) or channels-last padded to four

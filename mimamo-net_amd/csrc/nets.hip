@@ -148,6 +148,7 @@ static int run_layer(const Layer& L, const float* in, int B, int H, int W, int i
 
 // Stride-1 3x3 layer through Winograd F(2x2,3x3): input transform, ONE batched GEMM launch (16 problems), output
 // transform with the fused bias/ReLU.  V and M are caller-provided scratch of 16*B*ceil(H/2)*ceil(W/2)*C floats.
+static int g_wino_fused_max_cin = 128;   // measurement knob (MM_WF_MAX_CIN)
 static int g_wino_fused_shape = 0;   // measurement knob (MM_WINO_FUSED_SHAPE): workgroup shape of the fused kernel, 0 = auto
 
 static int run_layer_wino(const Layer& L, const float* in, int B, int H, int W, float* out, float* V, float* M, int m, hipStream_t s) {
@@ -290,7 +291,7 @@ int mm_resnet50_create(mm_resnet50_t** out, const float* blob, int64_t n_floats,
     h->device = current_device_or(0);
     const float* p = blob;
     int rc = MM_OK;
-    h->winograd = 4;
+    h->winograd = 1;
     auto conv_bn = [&](Layer& L, int cout, int cin, int k, int stride, int pad, int relu) {
         const float* w = p;
         p += (int64_t)cout * cin * k * k;
@@ -339,7 +340,9 @@ int64_t mm_resnet50_workspace_bytes(mm_resnet50_t* h, int64_t batch) {
 int mm_resnet50_set_winograd(mm_resnet50_t* h, int enable) {
     if (!h) return MM_ERR_INVALID_ARG;
     if (enable != 0 && enable != 1 && enable != 2 && enable != 4 && enable != 5) return MM_ERR_INVALID_ARG;
-    h->winograd = enable == 1 ? 4 : enable;   // 1 = default variant
+    h->winograd = enable;   // 1 = default: F(4x4,3x3), output transform fused into the GEMMs where that is faster (Cin <= 128)
+    const char* mc = getenv("MM_WF_MAX_CIN");
+    if (mc) mm::g_wino_fused_max_cin = atoi(mc);
     const char* sh = getenv("MM_WINO_FUSED_SHAPE");
     mm::g_wino_fused_shape = sh ? atoi(sh) : 0;
     return MM_OK;
@@ -399,7 +402,10 @@ int mm_resnet50_forward(mm_resnet50_t* h, const float* images, int nchw, int64_t
         }
         rc = run_layer(Bk.reduce, x, B, H, W, C, 0, y1, Bk.reduce.cout, 0, nullptr, 0, s, &H1, &W1);
         if (rc != MM_OK) return rc;
-        const int wm_ = h->winograd;
+        // default (1): conv2_x / conv3_x (Cin 64 / 128: position GEMMs bound by the M planes' HBM traffic) take the fused
+        // kernel, conv4_x / conv5_x the three-kernel form (their GEMMs are matrix-core bound and the fused kernel's
+        // one-wave-per-SIMD loop is slower there); measured per layer in DESIGN.md
+        const int wm_ = h->winograd == 1 ? (Bk.conv3.cin <= g_wino_fused_max_cin ? 5 : 4) : h->winograd;
         const int wt_ = wm_ == 5 ? 4 : wm_;   // tile side of the variant
         if (wm_ && Bk.conv3.wino_u &&
             (int64_t)(wt_ + 2) * (wt_ + 2) * ((H1 + wt_ - 1) / wt_) * ((W1 + wt_ - 1) / wt_) * Bk.conv3.cin <= kRsWino) {

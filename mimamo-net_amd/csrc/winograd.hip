@@ -1,9 +1,10 @@
-// Winograd F(2x2, 3x3) for the stride-1 3x3 convolutions of the ResNet50 trunk (conv3_x..conv5_x, 13 layers,
-// 38 % of the network's FLOPs): 2.25x fewer multiply-adds than the direct form for the same result up to fp32
-// rounding (input/output transforms use only additions; the weight transform is done once on the host in float64).
-//   V = B^T d B  per 4x4 input patch (stride 2, pad 1)     -- this file, memory-bound
-//   M_xi = V_xi * U_xi, xi = 0..15                         -- one BATCHED launch of the fp32 MFMA GEMM engine
-//   Y = A^T M A + bias, ReLU  per 2x2 output patch         -- this file, memory-bound
+// Winograd F(2x2,3x3) / F(4x4,3x3) transforms for the stride-1 3x3 convolutions of the ResNet50 trunk (conv2_x..conv5_x, 16
+// layers, 42 % of the network's direct-form FLOPs): 2.25x / 4x fewer multiply-adds than the direct form for the same result up
+// to fp32 rounding (the weight transform is done once on the host in float64).
+//   V = B^T d B  per (m+2)x(m+2) input patch (stride m, pad 1)     -- this file, memory-bound
+//   M_xi = V_xi * U_xi, xi = 0..(m+2)^2-1                           -- one BATCHED launch of the fp32 MFMA GEMM engine
+//   Y = A^T M A + bias, ReLU  per m x m output patch                -- this file, memory-bound
+// The default path of conv2_x / conv3_x replaces the last two steps by wino_fused.hip (output transform inside the GEMM kernel).
 // The reference computes these layers with torch's direct fp32 conv (third-party ResNet50, api/resnet50_extractor.py:
 // 74-83); parity is checked against the oracle's direct convolution.
 #include "conv.h"
