@@ -268,7 +268,7 @@ def parse_args(argv=None):
     ap.add_argument("--stub-compute", action="store_true", help="testing only: no GPU work (launcher / work-queue plumbing)")
     ap.add_argument("--dump-out", default="", help="testing only: rank 0 saves the gathered rows of the last step (.npy)")
     ap.add_argument("--no-winograd", action="store_true", help="run every 3x3 layer in the direct implicit-GEMM form")
-    ap.add_argument("--winograd", type=int, default=1, help="1 = default (F(4x4,3x3); conv2_x/conv3_x with the output transform fused into the position GEMMs), 2 = F(2x2,3x3), 4 = F(4x4,3x3) as three kernels everywhere, 5 = fused everywhere")
+    ap.add_argument("--winograd", type=int, default=1, help="1 = default (F(4x4,3x3); conv2_x..conv4_x with the output transform fused into the position GEMMs), 2 = F(2x2,3x3), 4 = F(4x4,3x3) as three kernels everywhere, 5 = fused everywhere")
     ap.add_argument("--lanes", type=int, default=3, help="HIP streams the clips of a step are spread over (1 = single stream)")
     ap.add_argument("--from-f32", action="store_true",
                     help="start every step from host-preprocessed fp32 tensors (gray 48x48, RGB 224x224) instead of the "
@@ -458,7 +458,7 @@ def run_rank(args):
 
     traffic = committed_traffic("r02_conv_traffic_%dclips.json")
     ptraffic = committed_traffic("r02_phase_traffic_%dclips.json")
-    wino = 0 if args.no_winograd else {1: "F(4x4,3x3); output transform fused into the GEMMs for Cin <= 128", 2: "F(2x2,3x3)", 4: "F(4x4,3x3), three kernels", 5: "F(4x4,3x3), fused everywhere"}.get(args.winograd, args.winograd)
+    wino = 0 if args.no_winograd else {1: "F(4x4,3x3); output transform fused into the GEMMs for Cin <= 256", 2: "F(2x2,3x3)", 4: "F(4x4,3x3), three kernels", 5: "F(4x4,3x3), fused everywhere"}.get(args.winograd, args.winograd)
     result["roofline"] = {
         "bound": "mfma", "kernel": "conv_mfma_kernel (fp32 implicit-GEMM conv/GEMM engine, all %d launches of one step)" % launches[0],
         "achieved": conv_tflops, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",

@@ -183,7 +183,7 @@ int mm_resnet50_destroy(mm_resnet50_t* h);
  * same result up to fp32 rounding).  mode: 0 = every layer in the direct implicit-GEMM form, 2 = F(2x2,3x3) as three kernels
  * (input transform, batched position GEMMs, output transform), 4 = F(4x4,3x3) as three kernels, 5 = F(4x4,3x3) with the output
  * transform fused into the position GEMMs (csrc/wino_fused.hip: the M planes never reach HBM), 1 = the default: variant 5 for
- * the layers with <= 128 input channels (conv2_x, conv3_x), variant 4 for the others. */
+ * the layers with <= 256 input channels (conv2_x..conv4_x), variant 4 for conv5_x. */
 int mm_resnet50_set_winograd(mm_resnet50_t* h, int enable);
 int64_t mm_resnet50_workspace_bytes(mm_resnet50_t* h, int64_t batch);
 /* images: device f32, [batch,3,224,224] (nchw=1, the reference's layout) or channels-last padded to four

@@ -148,7 +148,7 @@ static int run_layer(const Layer& L, const float* in, int B, int H, int W, int i
 
 // Stride-1 3x3 layer through Winograd F(2x2,3x3): input transform, ONE batched GEMM launch (16 problems), output
 // transform with the fused bias/ReLU.  V and M are caller-provided scratch of 16*B*ceil(H/2)*ceil(W/2)*C floats.
-static int g_wino_fused_max_cin = 128;   // measurement knob (MM_WF_MAX_CIN)
+static int g_wino_fused_max_cin = 256;   // measurement knob (MM_WF_MAX_CIN)
 static int g_wino_fused_shape = 0;   // measurement knob (MM_WINO_FUSED_SHAPE): workgroup shape of the fused kernel, 0 = auto
 
 static int run_layer_wino(const Layer& L, const float* in, int B, int H, int W, float* out, float* V, float* M, int m, hipStream_t s) {
@@ -340,7 +340,7 @@ int64_t mm_resnet50_workspace_bytes(mm_resnet50_t* h, int64_t batch) {
 int mm_resnet50_set_winograd(mm_resnet50_t* h, int enable) {
     if (!h) return MM_ERR_INVALID_ARG;
     if (enable != 0 && enable != 1 && enable != 2 && enable != 4 && enable != 5) return MM_ERR_INVALID_ARG;
-    h->winograd = enable;   // 1 = default: F(4x4,3x3), output transform fused into the GEMMs where that is faster (Cin <= 128)
+    h->winograd = enable;   // 1 = default: F(4x4,3x3), output transform fused into the GEMMs where that is faster (Cin <= 256)
     const char* mc = getenv("MM_WF_MAX_CIN");
     if (mc) mm::g_wino_fused_max_cin = atoi(mc);
     const char* sh = getenv("MM_WINO_FUSED_SHAPE");
@@ -402,9 +402,8 @@ int mm_resnet50_forward(mm_resnet50_t* h, const float* images, int nchw, int64_t
         }
         rc = run_layer(Bk.reduce, x, B, H, W, C, 0, y1, Bk.reduce.cout, 0, nullptr, 0, s, &H1, &W1);
         if (rc != MM_OK) return rc;
-        // default (1): conv2_x / conv3_x (Cin 64 / 128: position GEMMs bound by the M planes' HBM traffic) take the fused
-        // kernel, conv4_x / conv5_x the three-kernel form (their GEMMs are matrix-core bound and the fused kernel's
-        // one-wave-per-SIMD loop is slower there); measured per layer in DESIGN.md
+        // default (1): conv2_x..conv4_x (Cin <= 256) take the fused kernel, conv5_x the three-kernel form (Cin = 512: its
+        // position GEMMs are matrix-core bound, 135 vs 109 TFLOP/s, and its M planes are small); per layer in DESIGN.md
         const int wm_ = h->winograd == 1 ? (Bk.conv3.cin <= g_wino_fused_max_cin ? 5 : 4) : h->winograd;
         const int wt_ = wm_ == 5 ? 4 : wm_;   // tile side of the variant
         if (wm_ && Bk.conv3.wino_u &&

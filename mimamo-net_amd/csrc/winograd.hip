@@ -4,7 +4,7 @@
 //   V = B^T d B  per (m+2)x(m+2) input patch (stride m, pad 1)     -- this file, memory-bound
 //   M_xi = V_xi * U_xi, xi = 0..(m+2)^2-1                           -- one BATCHED launch of the fp32 MFMA GEMM engine
 //   Y = A^T M A + bias, ReLU  per m x m output patch                -- this file, memory-bound
-// The default path of conv2_x / conv3_x replaces the last two steps by wino_fused.hip (output transform inside the GEMM kernel).
+// The default path of conv2_x..conv4_x replaces the last two steps by wino_fused.hip (output transform inside the GEMM kernel).
 // The reference computes these layers with torch's direct fp32 conv (third-party ResNet50, api/resnet50_extractor.py:
 // 74-83); parity is checked against the oracle's direct convolution.
 #include "conv.h"

@@ -48,7 +48,8 @@ class Resnet50_Extractor(object):
         self._ws = {}   # per-stream workspaces: the handle itself is stateless, so lanes on different streams may share it
 
     def set_winograd(self, mode=True):
-        """Algorithm of the stride-1 3x3 layers of conv2_x..conv5_x: True/1 = default (Winograd F(4x4,3x3)),
+        """Algorithm of the stride-1 3x3 layers of conv2_x..conv5_x: True/1 = default (Winograd F(4x4,3x3): variant 5 for
+        conv2_x..conv4_x, variant 4 for conv5_x),
         2 = F(2x2,3x3), 4 = F(4x4,3x3) as three kernels (input transform, 36 batched GEMMs, output transform),
         5 = F(4x4,3x3) with the output transform fused into the position GEMMs (csrc/wino_fused.hip),
         False/0 = direct implicit GEMM."""
