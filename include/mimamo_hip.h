@@ -110,8 +110,11 @@ int mm_phase_extract_generic(const float* coeff, int64_t planes, int P, int R, i
 
 /* Fused, de-duplicated driver for one batch of frames (the build's fast path): pyramid once
  * per unique frame, then J windows gathered through window ids (snippet_sampler.py:144-152).
- * frames [n,size,size]; ids int32 [J*13] in [0,n).  Outputs as in mm_phase_extract for W=size
- * (out0) and W=size/2 (out1).  workspace: mm_phase_workspace_bytes(n) bytes of HBM. */
+ * frames [n,size,size]; ids int32 [J*13] in [0,n), each window a run of CONSECUTIVE frames with repeats only at its ends
+ * (ids[i+1] - ids[i] in {0, 1}: what the sampler's clamped windows are) -- the per-frame planes carry their unwrap
+ * decision relative to the preceding frame of the stack (csrc/phase_frames.hip); other index patterns go through
+ * mm_pyramid_build_batch + mm_phase_extract.  Outputs as in mm_phase_extract for W=size (out0) and W=size/2 (out1).
+ * workspace: mm_phase_workspace_bytes(n) bytes of HBM. */
 int64_t mm_phase_workspace_bytes(mm_pyramid_t* h, int64_t n);
 int mm_phase_diff_frames(mm_pyramid_t* h, const float* frames, int64_t n, const int32_t* ids, int64_t J,
                          float* out0, int out0_nhwc, int out0_cstride, int out0_coffset,

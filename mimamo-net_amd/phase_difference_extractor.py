@@ -154,9 +154,10 @@ class Phase_Difference_Extractor(object):
         Tester.phase_diff_output, identical results because the pyramid is per-frame -- quirk Q3).
         nhwc=True writes channels-last tensors ([J,W,W,24], [J,W/2,W/2,out1_cstride] with the 24 channels
         at out1_coffset) for the head's conv engine.
-        The ids index planes of the N-frame workspace: they are range-checked on the host the first time a table is
-        seen (one device->host read, cached per table); ids_checked=True skips that for tables the caller built
-        from the same frame count (HotPath.plan)."""
+        The ids index planes of the N-frame workspace and must step by 0 or +1 inside a window (the per-frame planes
+        carry their unwrap decision relative to the preceding frame, csrc/phase_frames.hip): both are checked on the host
+        the first time a table is seen (one device->host read, cached per table); ids_checked=True skips that for tables
+        the caller built from the same frame count (HotPath.plan)."""
         self._check_input(frames, 3, "frames")
         N, W, _ = frames.shape
         J = window_ids.shape[0]
@@ -164,9 +165,15 @@ class Phase_Difference_Extractor(object):
         if not ids_checked and J > 0:
             hit = self._ids_ok.get(id(window_ids))
             if not (hit is not None and hit[0]() is window_ids and hit[1] == (window_ids._version, N)):
-                lo, hi = int(window_ids.min().item()), int(window_ids.max().item())
+                step = window_ids[:, 1:] - window_ids[:, :-1]
+                chk = torch.stack([window_ids.min(), window_ids.max(), step.min(), step.max()]).tolist()   # one device->host read
+                lo, hi = int(chk[0]), int(chk[1])
                 if lo < 0 or hi >= N:
                     raise ValueError("window_ids must index the %d frames handed over (found %d..%d)" % (N, lo, hi))
+                if chk[2] < 0 or chk[3] > 1:
+                    raise ValueError("every window must be a run of consecutive frames with repeats only at its ends (clamped "
+                                     "windows, snippet_sampler.py:144-152): found index steps in %d..%d; use build_pyramid + "
+                                     "extract for other patterns" % (int(chk[2]), int(chk[3])))
                 if len(self._ids_ok) > 64:
                     self._ids_ok.clear()
                 self._ids_ok[id(window_ids)] = (weakref.ref(window_ids), (window_ids._version, N))

@@ -35,10 +35,13 @@ def _windows():
 
 
 def _phase_err(a, b):
-    """max / p99.99 abs error ignoring isolated 2*pi branch flips (counted separately)."""
+    """max / p99.99 abs error ignoring isolated 2*pi branch flips (counted separately).  The observed numbers are printed
+    (pytest -s) so that a regression inside the allowance is visible."""
     d = np.abs(a - b)
     flips = d > 1.0
-    return d[~flips].max(), np.quantile(d[~flips], 0.9999), int(flips.sum())
+    res = d[~flips].max(), np.quantile(d[~flips], 0.9999), int(flips.sum())
+    print("phase error: max %.2e  p99.99 %.2e  2pi branch flips %d of %d" % (res + (d.size,)))
+    return res
 
 
 def test_pyramid_golden(pde, golden, dev):
@@ -101,7 +104,12 @@ def test_dedup_fast_path_matches_drop_in(pde, oracle, dev):
     i = torch.from_numpy(ids).to(dev)
     a0, a1 = pde.phase_diff_frames(f, i)
     b0, b1 = phase_diff_output(f[i.long()][None], pde)
-    assert torch.equal(a0, b0[0]) and torch.equal(a1, b1[0])  # same kernels, same per-frame pyramid: bit-identical
+    # same per-frame pyramid; the fast path evaluates blur(mag (phase + acc)) / blur(mag) as B + blur(mag acc) R with B, R per
+    # unique frame (csrc/phase_frames.hip): equal up to fp32 rounding of that regrouping, with no branch flips between the two
+    for fast, lit in ((a0, b0[0]), (a1, b1[0])):
+        diff = (fast - lit).abs()
+        print("fast path vs literal kernel: max |diff| %.2e, mean %.2e" % (diff.max().item(), diff.mean().item()))
+        assert diff.max().item() < 5e-5 and diff.mean().item() < 2e-6
     # channels-last variant used by the head's conv engine
     n0, n1 = pde.phase_diff_frames(f, i, nhwc=True, out1_cstride=88, out1_coffset=64)
     assert torch.equal(n0.permute(0, 3, 1, 2), a0)

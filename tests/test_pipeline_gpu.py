@@ -182,8 +182,8 @@ def test_reference_style_dataloader_loop_matches_fused_path(tester, oracle):
     res = tester.test_on_dataloader([batch])
     fused = tester.test_frames([clip], names=["v"])
     assert res["v"].shape == (n, 2)
-    # same kernels; only the pyramid de-duplication differs, which is exact per frame
-    np.testing.assert_array_equal(res["v"].values, fused["v"].values)
+    # same pyramid per frame; the fused path regroups the blurred ratio per unique frame (csrc/phase_frames.hip): fp32 rounding only
+    assert np.abs(res["v"].values - fused["v"].values).max() < 5e-6
 
 
 def test_equal_shaped_videos_share_one_gru_call_and_match_per_video_calls(tester):
