@@ -37,6 +37,15 @@ inline int current_device_or(int fallback) {
         if (mm::current_device_or(-1) != (h)->device) return MM_ERR_INVALID_ARG; \
     } while (0)
 
+// XCD-aware work order: workgroup b runs on XCD b % 8 (each XCD has its own L2).  Returns the logical work item of block b so that
+// every XCD walks a CONTIGUOUS run of items: neighbours that share operands (n-tiles of one m-tile, consecutive 13-frame windows)
+// then share an L2 instead of being fetched by all eight.
+__device__ __forceinline__ int xcd_contiguous(int b, int nblk) {
+    const int xcd = b & 7, idx = b >> 3;
+    const int q = nblk >> 3, r = nblk & 7;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+}
+
 // ---- optional launch timing (profile.hip)
 bool prof_enabled();
 void prof_before(int cat, double work, hipStream_t s, const char* tag = nullptr);

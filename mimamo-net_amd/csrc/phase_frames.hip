@@ -146,8 +146,10 @@ phase_window2_kernel(const float* __restrict__ fr, const int32_t* __restrict__ i
     float* tmp_x = in_x + C::IN_PLANE;
     float* red = tmp_x + C::TMP_PLANE;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int64_t j = blockIdx.x >> 1;
-    const int band = blockIdx.x & 1;
+    // consecutive windows share 12 of their 13 frames: keep them on one XCD (one L2) instead of spreading them over all eight
+    const int logical = xcd_contiguous(blockIdx.x, gridDim.x);
+    const int64_t j = logical >> 1;
+    const int band = logical & 1;
     const bool active = tid < C::ACTIVE;
     const int y = active ? tid / C::STRIPS : 0;
     const int x0 = active ? (tid - y * C::STRIPS) * PX : 0;

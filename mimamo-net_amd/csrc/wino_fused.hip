@@ -54,7 +54,9 @@ wino_fused_kernel(const WinoFusedParams p) {
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;               // 16 tiles x 32 channels per wave
     const int l16 = lane & 15, lg = lane >> 4;             // MFMA operand row / column, k index inside a k-step of 4
-    const int tile_m = blockIdx.x / p.tiles_n, tile_n = blockIdx.x - tile_m * p.tiles_n;
+    // the n-tiles of an m-tile are neighbours in the logical order and stay on one XCD: its L2 serves the V rows they share
+    const int logical = xcd_contiguous(blockIdx.x, gridDim.x);
+    const int tile_m = logical / p.tiles_n, tile_n = logical - tile_m * p.tiles_n;
     const int m_base = tile_m * BM, n_base = tile_n * BN;
     const int K = p.K, kslabs = K / KS;
 
