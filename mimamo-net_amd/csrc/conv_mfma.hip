@@ -415,11 +415,12 @@ int conv_forward(const ConvParams& p0, hipStream_t stream) {
     ConvParams p = p0;
     if (p.Cin % 4 || p.in_cstride % 4 || p.in_coff % 4 || p.Kpad % CBK || p.K > p.Kpad) return MM_ERR_INVALID_ARG;
     if (p.korder != 0 && (p.korder != 1 || p.Cin % CBK)) return MM_ERR_INVALID_ARG;
-    // 32-bit byte offsets inside the kernel: the weight matrix, and the few images one 128-row block spans
+    // 32-bit byte offsets inside the kernel: the weight matrix, and the few images one block spans (the A descriptor is rebased to
+    // the block's first image; the largest block tile is 256 rows -- force_tile 4)
     if ((uint64_t)p.Cout * p.Kpad * 4 >= 0xFFFFF000ull) return MM_ERR_INVALID_ARG;
     {
         const int64_t hw_o = (int64_t)p.Ho * p.Wo;
-        const int64_t span = 128 / (hw_o > 0 ? hw_o : 1) + 2;
+        const int64_t span = 256 / (hw_o > 0 ? hw_o : 1) + 2;
         if (span * p.H * p.W * p.in_cstride * 4 >= 0x7FFFF000ll) return MM_ERR_INVALID_ARG;
     }
     p.M = p.B * p.Ho * p.Wo;

@@ -162,3 +162,26 @@ def test_bench_refuses_to_run_without_a_gpu():
         pytest.skip("GPU host")
     r, d = _run_bench("--steps", 1, "--no-cpu-baseline")
     assert r.returncode != 0 and d is None and "no CPU path" in r.stderr
+
+
+def test_bench_under_torchrun_as_the_driver_launches_it():
+    """`python -m torch.distributed.run --nproc-per-node 2 ... bench.py --gpus 2`: ranks come from the launcher's environment,
+    rank 0 prints the one JSON line."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                        "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2",
+                        "--warmup", "1", "--clips", "2", "--stub-compute"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                       universal_newlines=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["config"]["work_queue"]["total_clips"] == 10000
