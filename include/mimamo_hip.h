@@ -201,13 +201,18 @@ int mm_resnet50_forward(mm_resnet50_t* h, const float* images, int nchw, int64_t
  * (num_batches_tracked skipped); see weights.py `two_stream_blob`. */
 int64_t mm_head_blob_floats(void);
 int mm_head_create(mm_head_t** out, const float* host_blob, int64_t n_floats);
+/* The same with another MLP on the ResNet feature stream: units = Two_Stream_RNN's mlp_hidden_units (api/mimamo_net.py:6-26,
+ * 97-98), e.g. {2048, 512, 256}: n_units >= 2, units[last] == 256 (the reference asserts it), every entry a multiple of 4;
+ * the rgb input of mm_head_forward is then [bs, T, units[0]].  mm_head_create == units {2048, 256, 256} (api/tester.py:45). */
+int64_t mm_head_blob_floats_mlp(int n_units, const int* units);
+int mm_head_create_mlp(mm_head_t** out, const float* host_blob, int64_t n_floats, int n_units, const int* units);
 int mm_head_destroy(mm_head_t* h);
 int64_t mm_head_workspace_bytes(mm_head_t* h, int64_t bs, int64_t T);
 /* phase_0 [bs,T,24,48,48] / phase_1 [bs,T,24,24,24] (phase_nhwc=0, reference layout) or
  * NHWC [bs*T,48,48,24] / [bs*T,24,24,24] (phase_nhwc=1), or NHWC with phase_1 already placed at channels
  * 64..87 of a [bs*T,24,24,88] buffer that the call then completes in place (phase_nhwc=2, the fused
  * pipeline: PhaseNet concatenates conv features and level-1 phase, mimamo_net.py:85);
- * rgb [bs,T,2048]; out [bs,T,2]
+ * rgb [bs,T,2048] ([bs,T,units[0]] for mm_head_create_mlp); out [bs,T,2]
  * (col 0 valence, col 1 arousal, tester.py:52).  The GRU runs over dim 0 (bs) with T as its
  * batch, exactly like nn.GRU without batch_first (mimamo_net.py:119,139; quirk Q1). */
 int mm_head_forward(mm_head_t* h, const float* phase_0, const float* phase_1, int phase_nhwc,

@@ -209,7 +209,9 @@ struct mm_resnet50 {
 
 struct mm_head {
     mm::DeviceArena arena;
-    mm::Layer mlp1, mlp2, conv[6], fc1, fc2, transform, gru_ih[2], gru_hh[2][2], classifier;
+    std::vector<mm::Layer> mlp;   // MLP(hidden_units): Linear -> BN -> ReLU per layer (api/mimamo_net.py:6-26); published: 2048 -> 256 -> 256
+    int feat_dim, mlp_max;        // hidden_units[0] (width of the rgb features), widest hidden layer
+    mm::Layer conv[6], fc1, fc2, transform, gru_ih[2], gru_hh[2][2], classifier;
     float* bhh[2][2];
     int device;
 };
@@ -235,11 +237,21 @@ static int64_t resnet_blob_floats() {
 static const int64_t kRsIn4 = 224 * 224 * 4, kRsBig = 112 * 112 * 64, kRsMid = 56 * 56 * 128;
 static const int64_t kRsWino = 36 * 14 * 14 * 64;   // largest Winograd plane set: conv2_x under F(4x4,3x3) (> kRsMid)
 
-static int64_t head_blob_floats() {
+static const int kMlpPublished[3] = {2048, 256, 256};   // api/tester.py:45
+
+// hidden_units as api/mimamo_net.py:7-12 takes them: >= 2 entries, last == 256; here also multiples of 4 (16-byte channel groups)
+static bool mlp_units_ok(int n_units, const int* units) {
+    if (n_units < 2 || n_units > 16 || !units || units[n_units - 1] != 256) return false;
+    for (int i = 0; i < n_units; ++i)
+        if (units[i] <= 0 || units[i] % 4 || units[i] > 65536) return false;
+    return true;
+}
+
+static int64_t head_blob_floats(int n_units, const int* units) {
     int64_t n = 0;
     auto lin = [&](int o, int i) { n += (int64_t)o * i + o; };
     auto bn = [&](int c) { n += 4 * c; };
-    lin(256, 2048); bn(256); lin(256, 256); bn(256);
+    for (int i = 1; i < n_units; ++i) { lin(units[i], units[i - 1]); bn(units[i]); }
     const int ch[3][2] = {{24, 64}, {88, 128}, {128, 256}};
     for (auto& c : ch) { n += (int64_t)c[1] * c[0] * 9 + c[1]; bn(c[1]); n += (int64_t)c[1] * c[1] * 9 + c[1]; bn(c[1]); }
     lin(256, 256); bn(256); lin(256, 256); bn(256); lin(1, 256); bn(1);
@@ -425,13 +437,22 @@ int mm_resnet50_forward(mm_resnet50_t* h, const float* images, int nchw, int64_t
 }
 
 // ============================================ head =====================================================
-int64_t mm_head_blob_floats(void) { return mm::head_blob_floats(); }
+int64_t mm_head_blob_floats(void) { return mm::head_blob_floats(3, mm::kMlpPublished); }
+
+int64_t mm_head_blob_floats_mlp(int n_units, const int* units) {
+    return mm::mlp_units_ok(n_units, units) ? mm::head_blob_floats(n_units, units) : (int64_t)MM_ERR_INVALID_ARG;
+}
 
 int mm_head_create(mm_head_t** out, const float* blob, int64_t n_floats) {
+    return mm_head_create_mlp(out, blob, n_floats, 3, mm::kMlpPublished);
+}
+
+int mm_head_create_mlp(mm_head_t** out, const float* blob, int64_t n_floats, int n_units, const int* units) {
     using namespace mm;
     if (!out) return MM_ERR_INVALID_ARG;
     *out = nullptr;
-    if (!blob || n_floats != head_blob_floats()) return MM_ERR_INVALID_ARG;
+    if (!mlp_units_ok(n_units, units)) return MM_ERR_INVALID_ARG;
+    if (!blob || n_floats != head_blob_floats(n_units, units)) return MM_ERR_INVALID_ARG;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return MM_ERR_NO_DEVICE;
     mm_head* h = new (std::nothrow) mm_head();
@@ -457,8 +478,13 @@ int mm_head_create(mm_head_t** out, const float* blob, int64_t n_floats) {
         const float* w = take((int64_t)o * i); const float* b = take(o); BN bn = take_bn(o);
         if (rc == MM_OK) rc = make_layer(h->arena, L, w, b, o, i, 1, 1, 0, 1, nullptr, &bn, eps);
     };
-    lin_bn_relu(h->mlp1, 256, 2048);
-    lin_bn_relu(h->mlp2, 256, 256);
+    h->feat_dim = units[0];
+    h->mlp_max = 256;
+    h->mlp.resize(n_units - 1);
+    for (int i = 1; i < n_units; ++i) {
+        lin_bn_relu(h->mlp[i - 1], units[i], units[i - 1]);
+        if (units[i] > h->mlp_max) h->mlp_max = units[i];
+    }
     const int ch[3][2] = {{24, 64}, {88, 128}, {128, 256}};
     for (int i = 0; i < 3; ++i) {
         conv_bn_relu(h->conv[2 * i], ch[i][1], ch[i][0], 1);
@@ -507,11 +533,11 @@ namespace {
 struct HeadWs {
     int64_t p0n, a0, cat, a1, a2, a3, a4, pool, fc1, m1, feat, f, gi, gh, l0, l1;
 };
-HeadWs head_sizes(int64_t N, int64_t T) {
+HeadWs head_sizes(int64_t N, int64_t T, int64_t mlp_max) {
     HeadWs s;
     s.p0n = N * 48 * 48 * 24; s.a0 = N * 48 * 48 * 64; s.cat = N * 24 * 24 * 88; s.a1 = N * 24 * 24 * 128;
     s.a2 = N * 12 * 12 * 128; s.a3 = N * 12 * 12 * 256; s.a4 = N * 6 * 6 * 256; s.pool = N * 256; s.fc1 = N * 256;
-    s.m1 = N * 256; s.feat = N * 512; s.f = N * 256; s.gi = N * 768; s.gh = T * 384; s.l0 = N * 256; s.l1 = N * 256;
+    s.m1 = 2 * N * mlp_max; s.feat = N * 512; s.f = N * 256; s.gi = N * 768; s.gh = T * 384; s.l0 = N * 256; s.l1 = N * 256;
     return s;
 }
 }  // namespace
@@ -519,7 +545,7 @@ HeadWs head_sizes(int64_t N, int64_t T) {
 int64_t mm_head_workspace_bytes(mm_head_t* h, int64_t bs, int64_t T) {
     using mm::Bump;
     if (!h || bs < 0 || T < 0) return MM_ERR_INVALID_ARG;
-    const HeadWs s = head_sizes(bs * T, T);
+    const HeadWs s = head_sizes(bs * T, T, h->mlp_max);
     const int64_t all[] = {s.p0n, s.a0, s.cat, s.a1, s.a2, s.a3, s.a4, s.pool, s.fc1, s.m1, s.feat, s.f, s.gi, s.gh, s.l0, s.l1};
     int64_t tot = 0;
     for (int64_t v : all) tot += Bump::size_of(v);
@@ -537,7 +563,7 @@ int mm_head_forward(mm_head_t* h, const float* phase_0, const float* phase_1, in
     MM_CHECK_DEVICE(h);
     hipStream_t s = (hipStream_t)stream_;
     const int N = (int)N64;
-    const HeadWs z = head_sizes(N64, T);
+    const HeadWs z = head_sizes(N64, T, h->mlp_max);
     Bump ws(workspace, workspace_bytes);
     float* p0n = ws.take(z.p0n); float* a0 = ws.take(z.a0); float* cat = ws.take(z.cat); float* a1 = ws.take(z.a1);
     float* a2 = ws.take(z.a2); float* a3 = ws.take(z.a3); float* a4 = ws.take(z.a4); float* pool = ws.take(z.pool);
@@ -570,8 +596,17 @@ int mm_head_forward(mm_head_t* h, const float* phase_0, const float* phase_1, in
     MM_TRY(run_layer(h->fc1, pool, N, 1, 1, 256, 0, fc1, 256, 0, nullptr, 0, s));
     MM_TRY(run_layer(h->fc2, fc1, N, 1, 1, 256, 0, feat, 512, 256, nullptr, 0, s));  // cat([spatial, temporal]) (:136)
     // ---- spatial stream: MLP (:22-26)
-    MM_TRY(run_layer(h->mlp1, rgb, N, 1, 1, 2048, 0, m1, 256, 0, nullptr, 0, s));
-    MM_TRY(run_layer(h->mlp2, m1, N, 1, 1, 256, 0, feat, 512, 0, nullptr, 0, s));
+    {
+        const float* xin = rgb;
+        int cin = h->feat_dim;
+        for (size_t i = 0; i < h->mlp.size(); ++i) {
+            const bool last = i + 1 == h->mlp.size();
+            float* dst = last ? feat : m1 + (i & 1) * N64 * h->mlp_max;     // the last layer writes the spatial half of `feat`
+            MM_TRY(run_layer(h->mlp[i], xin, N, 1, 1, cin, 0, dst, last ? 512 : h->mlp[i].cout, 0, nullptr, 0, s));
+            xin = dst;
+            cin = h->mlp[i].cout;
+        }
+    }
     MM_TRY(run_layer(h->transform, feat, N, 1, 1, 512, 0, f, 256, 0, nullptr, 0, s));
     // ---- nn.GRU(256,128,bidirectional,num_layers=2) WITHOUT batch_first: the [bs,T,256] tensor is read as
     //      (seq_len = bs, batch = T)  (:119,139 -- quirk Q1, trained in, reproduced on purpose)

@@ -14,11 +14,16 @@ from . import _lib, weights
 class Two_Stream_RNN(object):
     def __init__(self, mlp_hidden_units=[2048, 256, 256], dropout=0.5, label_name='arousal_valence', num_phase=12):
         """Arguments as api/mimamo_net.py:97-122.  label_name in {'arousal', 'valence', 'arousal_valence'} sets the width
-        of the output layer (len(label_name.split('_')), :120-122).  mlp_hidden_units other than the published
-        [2048, 256, 256] (api/tester.py:45) and num_phase != 12 are not built into the library."""
-        if list(mlp_hidden_units) != [2048, 256, 256] or num_phase != 12:
-            raise NotImplementedError("this build implements the published trunk (mlp [2048,256,256], num_phase=12; "
-                                      "api/tester.py:45)")
+        of the output layer (len(label_name.split('_')), :120-122); mlp_hidden_units = [feature width, hidden..., 256]
+        (the reference's MLP asserts the last entry, :12; here every entry must also be a multiple of 4).  num_phase != 12
+        changes PhaseNet's input channels and is not built into the library."""
+        if num_phase != 12:
+            raise NotImplementedError("this build implements PhaseNet for num_phase=12 (api/tester.py:28)")
+        self.mlp_units = tuple(int(u) for u in mlp_hidden_units)
+        assert len(self.mlp_units) - 1 > 0          # api/mimamo_net.py:11
+        assert self.mlp_units[-1] == 256            # api/mimamo_net.py:12
+        if any(u <= 0 or u % 4 for u in self.mlp_units):
+            raise NotImplementedError("mlp_hidden_units must be positive multiples of 4 (16-byte channel groups)")
         if label_name not in ('arousal', 'valence', 'arousal_valence'):
             raise ValueError("label_name must be one of 'arousal', 'valence', 'arousal_valence' (api/mimamo_net.py:106)")
         self.label_name = label_name
@@ -35,12 +40,12 @@ class Two_Stream_RNN(object):
         return dict(self._state) if self._state is not None else {}
 
     def load_state_dict(self, state_dict, strict=True):
-        keys = weights.two_stream_float_keys()
+        keys = weights.two_stream_float_keys(self.mlp_units)
         missing = [k for k in keys if k not in state_dict]
         if missing:
             raise RuntimeError("Error(s) in loading state_dict for Two_Stream_RNN: Missing key(s): %s" % missing[:4])
         if strict:
-            known = set(keys) | {k + ".num_batches_tracked" for k in weights.TWO_STREAM_BN_KEYS}
+            known = set(keys) | {k + ".num_batches_tracked" for k in weights.two_stream_bn_keys(self.mlp_units)}
             extra = [k for k in state_dict if k not in known]
             if extra:
                 raise RuntimeError("Error(s) in loading state_dict for Two_Stream_RNN: Unexpected key(s): %s" % extra[:4])
@@ -50,7 +55,7 @@ class Two_Stream_RNN(object):
                 raise RuntimeError("Error(s) in loading state_dict for Two_Stream_RNN: size mismatch for %s: checkpoint has %d "
                                    "outputs, label_name=%r needs %d" % (k, tuple(state_dict[k].shape)[0], self.label_name, self.n_out))
         self._state = {k: v for k, v in state_dict.items()}
-        self._blob = weights.two_stream_blob(weights.widen_classifier(state_dict) if self.n_out == 1 else state_dict)
+        self._blob = weights.two_stream_blob(weights.widen_classifier(state_dict) if self.n_out == 1 else state_dict, self.mlp_units)
         self._release()
         return self
 
@@ -100,14 +105,16 @@ class Two_Stream_RNN(object):
                 self.device = torch.device('cuda', torch.cuda.current_device())
             h = ctypes.c_void_p()
             with torch.cuda.device(self.device):
-                rc = _lib.lib().mm_head_create(ctypes.byref(h), self._blob.ctypes.data_as(ctypes.c_void_p), self._blob.size)
-            _lib.check(rc, "mm_head_create")
+                units = (ctypes.c_int * len(self.mlp_units))(*self.mlp_units)
+                rc = _lib.lib().mm_head_create_mlp(ctypes.byref(h), self._blob.ctypes.data_as(ctypes.c_void_p), self._blob.size,
+                                                   len(self.mlp_units), units)
+            _lib.check(rc, "mm_head_create_mlp")
             self._handle = h
         return self._handle
 
     # -- forward ---------------------------------------------------------------------------------
     def forward(self, phase_data, rgb_data, phase_layout="nchw"):
-        """phase_data = [phase_0 [bs,T,24,48,48], phase_1 [bs,T,24,24,24]], rgb_data [bs,T,2048] -> [bs,T,n_out]
+        """phase_data = [phase_0 [bs,T,24,48,48], phase_1 [bs,T,24,24,24]], rgb_data [bs,T,mlp_hidden_units[0]] -> [bs,T,n_out]
         (n_out = 2 for 'arousal_valence', 1 for 'arousal' / 'valence').
 
         phase_layout: "nchw" (reference), "nhwc" ([bs*T,48,48,24] / [bs*T,24,24,24]) or "nhwc_cat"
@@ -129,7 +136,7 @@ class Two_Stream_RNN(object):
             assert tuple(phase_0.shape) == (bs * T, 48, 48, 24) and tuple(phase_1.shape) == (bs * T, 24, 24, 24)
         else:
             assert tuple(phase_0.shape) == (bs * T, 48, 48, 24) and tuple(phase_1.shape) == (bs * T, 24, 24, 88)
-        assert rgb_data.size(2) == 2048
+        assert rgb_data.size(2) == self.mlp_units[0]
         phase_0, phase_1, rgb = phase_0.contiguous(), phase_1.contiguous(), rgb_data.contiguous()
         out = torch.empty((bs, T, 2), dtype=torch.float32, device=rgb.device)
         L = _lib.lib()

@@ -68,20 +68,28 @@ def _conv(sd, prefix, cout, cin, k, seed, bias=True, gain=1.0):
         sd[prefix + ".bias"] = det_uniform(prefix + ".bias", (cout,), -0.05, 0.05, seed)
 
 
+MLP_PUBLISHED = (2048, 256, 256)   # api/tester.py:45
+
+
+def two_stream_bn_keys(mlp_units=MLP_PUBLISHED):
+    """BatchNorm modules of Two_Stream_RNN in module order (each also owns an int64 `num_batches_tracked`)."""
+    return tuple("mlp.mlp.%d" % (4 * i + 2) for i in range(len(mlp_units) - 1)) + TWO_STREAM_BN_KEYS[2:]
+
+
 TWO_STREAM_BN_KEYS = ("mlp.mlp.2", "mlp.mlp.6", "phasenet.conv_net.0.1", "phasenet.conv_net.0.4",
                       "phasenet.conv_net.1.1", "phasenet.conv_net.1.4", "phasenet.conv_net.2.1",
                       "phasenet.conv_net.2.4", "phasenet.fc.2", "phasenet.fc.6", "phasenet.classifier.1",
                       "transform.2", "classifier.2")
 
 
-def make_two_stream_state_dict(seed=0, num_phase=12, n_out=2):
+def make_two_stream_state_dict(seed=0, num_phase=12, n_out=2, mlp_units=MLP_PUBLISHED):
     """Random-init state_dict with the exact key/shape layout of Two_Stream_RNN (107 tensors
-    incl. the 13 `num_batches_tracked` counters).  n_out = len(label_name.split('_'))."""
+    incl. the 13 `num_batches_tracked` counters for the published configuration).  n_out = len(label_name.split('_'));
+    mlp_units = mlp_hidden_units (api/mimamo_net.py:6-26: Linear at Sequential index 4i+1, BatchNorm1d at 4i+2)."""
     sd = {}
-    _lin(sd, "mlp.mlp.1", 256, 2048, seed)
-    _bn(sd, "mlp.mlp.2", 256, seed)
-    _lin(sd, "mlp.mlp.5", 256, 256, seed)
-    _bn(sd, "mlp.mlp.6", 256, seed)
+    for i in range(len(mlp_units) - 1):
+        _lin(sd, "mlp.mlp.%d" % (4 * i + 1), mlp_units[i + 1], mlp_units[i], seed)
+        _bn(sd, "mlp.mlp.%d" % (4 * i + 2), mlp_units[i + 1], seed)
     nch = 2 * num_phase
     chans = [(nch, 64), (nch + 64, 128), (128, 256)]
     for i, (cin, cout) in enumerate(chans):
@@ -107,7 +115,7 @@ def make_two_stream_state_dict(seed=0, num_phase=12, n_out=2):
                 sd[key] = det_uniform(key, shape, -k, k, seed)
     _lin(sd, "classifier.1", n_out, 256, seed)
     _bn(sd, "classifier.2", n_out, seed)
-    for bn in TWO_STREAM_BN_KEYS:
+    for bn in two_stream_bn_keys(mlp_units):
         sd[bn + ".num_batches_tracked"] = np.zeros((), dtype=np.int64)
     return sd
 
@@ -173,15 +181,15 @@ def resnet50_blob(state_dict):
     return np.concatenate(parts)
 
 
-TWO_STREAM_FLOAT_KEYS = None
+_FLOAT_KEYS = {}
 
 
-def two_stream_float_keys():
+def two_stream_float_keys(mlp_units=MLP_PUBLISHED):
     """state_dict keys of Two_Stream_RNN in module order, without the int64 BN counters."""
-    global TWO_STREAM_FLOAT_KEYS
-    if TWO_STREAM_FLOAT_KEYS is None:
-        TWO_STREAM_FLOAT_KEYS = [k for k in make_two_stream_state_dict(0) if not k.endswith("num_batches_tracked")]
-    return TWO_STREAM_FLOAT_KEYS
+    mlp_units = tuple(int(u) for u in mlp_units)
+    if mlp_units not in _FLOAT_KEYS:
+        _FLOAT_KEYS[mlp_units] = [k for k in make_two_stream_state_dict(0, mlp_units=mlp_units) if not k.endswith("num_batches_tracked")]
+    return _FLOAT_KEYS[mlp_units]
 
 
 def widen_classifier(state_dict):
@@ -200,5 +208,5 @@ def widen_classifier(state_dict):
     return sd
 
 
-def two_stream_blob(state_dict):
-    return np.concatenate([_np(state_dict[k]) for k in two_stream_float_keys()])
+def two_stream_blob(state_dict, mlp_units=MLP_PUBLISHED):
+    return np.concatenate([_np(state_dict[k]) for k in two_stream_float_keys(mlp_units)])

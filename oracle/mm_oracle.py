@@ -371,11 +371,14 @@ def _to_torch_sd(sd, dtype=torch.float32):
 
 
 def mlp_forward(sd, rgb):
-    """MLP (mimamo_net.py:6-26), eval mode: Linear,BN,ReLU x2.  rgb [n,2048] -> [n,256]."""
-    x = F.linear(rgb, sd["mlp.mlp.1.weight"], sd["mlp.mlp.1.bias"])
-    x = F.relu(_bn(x, sd, "mlp.mlp.2"))
-    x = F.linear(x, sd["mlp.mlp.5.weight"], sd["mlp.mlp.5.bias"])
-    return F.relu(_bn(x, sd, "mlp.mlp.6"))
+    """MLP(hidden_units) (mimamo_net.py:6-26), eval mode: [Dropout, Linear, BatchNorm1d, ReLU] per hidden layer, i.e. Linear at
+    index 4i+1 and BN at 4i+2 of the Sequential.  rgb [n, hidden_units[0]] -> [n, 256]."""
+    x, i = rgb, 0
+    while ("mlp.mlp.%d.weight" % (4 * i + 1)) in sd:
+        x = F.linear(x, sd["mlp.mlp.%d.weight" % (4 * i + 1)], sd["mlp.mlp.%d.bias" % (4 * i + 1)])
+        x = F.relu(_bn(x, sd, "mlp.mlp.%d" % (4 * i + 2)))
+        i += 1
+    return x
 
 
 def phasenet_forward(sd, p0, p1):

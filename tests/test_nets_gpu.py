@@ -401,3 +401,22 @@ def test_winograd_error_where_it_can_hurt(oracle, dev, case):
     assert d[0] < 1e-4 and d[1] < 1e-5 and d[2] < OUT_ATOL, d                  # the direct form holds the stated bounds
     assert w2[0] < 1e-4 and w2[1] < 1e-5 and w2[2] < OUT_ATOL, w2
     assert w4[0] < 1e-4 and w4[1] < 1e-5 and w4[2] < OUT_ATOL, w4              # F(4x4,3x3) stays the default only if it does too
+
+
+@pytest.mark.parametrize("units", [[2048, 512, 256], [1024, 256], [2048, 384, 128, 256]])
+def test_head_mlp_hidden_units_variants(oracle, dev, units):
+    """Two_Stream_RNN(mlp_hidden_units=...) (api/mimamo_net.py:6-26,97-98): any number of Linear-BN-ReLU layers ending at 256,
+    any feature width; state_dict keys mlp.mlp.{4i+1,4i+2}.*"""
+    from mimamo_net_amd.mimamo_net import Two_Stream_RNN
+    sd = weights.make_two_stream_state_dict(seed=9, mlp_units=units)
+    assert ("mlp.mlp.%d.weight" % (4 * (len(units) - 2) + 1)) in sd
+    m = Two_Stream_RNN(mlp_hidden_units=units).load_state_dict(sd).eval().to(dev)
+    p0, p1, _ = _head_inputs(2, 8, 33)
+    rgb = weights.det_uniform("head.rgb2", (2, 8, units[0]), 0.0, 2.0, 33)
+    y = m([torch.from_numpy(p0).to(dev), torch.from_numpy(p1).to(dev)], torch.from_numpy(rgb).to(dev)).cpu().numpy()
+    want = oracle.two_stream_forward(sd, p0, p1, rgb)
+    assert y.shape == (2, 8, 2) and np.abs(y - want).max() < 2e-5
+    with pytest.raises(AssertionError):
+        Two_Stream_RNN(mlp_hidden_units=[2048, 128])          # the reference asserts hidden_units[-1] == 256
+    with pytest.raises(RuntimeError, match="Missing key"):
+        Two_Stream_RNN(mlp_hidden_units=units + [256]).load_state_dict(sd)
