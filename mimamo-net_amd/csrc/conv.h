@@ -42,10 +42,10 @@ int wino_input_transform(const float* x, float* V, int B, int H, int W, int C, i
 int wino_output_transform(const float* M, const float* bias, float* y, int B, int H, int W, int Cout, int relu, int m, hipStream_t s);
 
 // F(4x4,3x3) position GEMMs + output transform in one kernel (wino_fused.hip): V [36][tiles][Cin] (wino_input_transform, m = 4),
-// U [36][Cout][Cin] -> y NHWC + bias, ReLU.  ring: depth of the LDS slab ring (0 / 3 default, 4).
+// U [36][Cout][Cin] -> y NHWC + bias, ReLU.  shape: workgroup variant (0 default, see wino_fused.hip; measurement knob).
 // Needs Cin % 64 == 0 and Cout % 32 == 0 (MM_ERR_UNSUPPORTED otherwise).
 int wino_gemm_output_fused(const float* V, const float* U, const float* bias, float* y, int B, int H, int W, int Cin, int Cout,
-                           int relu, int ring, hipStream_t s);
+                           int relu, int shape, hipStream_t s);
 
 // one GRU time step for a batch of Bt rows (PyTorch gate order r,z,n):
 //   gi [Bt, gi_stride] (+gi_off) = W_ih x + b_ih ; gh [Bt, 3H] = W_hh h + b_hh (or null with bhh => h == 0)

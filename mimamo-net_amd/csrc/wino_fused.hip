@@ -8,8 +8,8 @@
 //     t[p]    += At[p][r] * M_xi        (r = 0..5, for the current column q)        VALU
 //     Y[p][q'] += At[q'][q] * t[p]      (once per column q)                          16 output pixels per tile
 // and stores Y + bias (+ReLU) as the layer's NHWC output.  A wave owns 16 tiles x 32 channels: Y = 128 registers, t = 32, so
-// two waves share a SIMD (8 waves = 4 x 2 per workgroup, one workgroup per CU) and one wave's loads, transform VALU and
-// barrier waits run under the other's MFMAs.  Operands stream global -> LDS directly (buffer_load ... lds) in 64-deep K slabs
+// two waves share a SIMD (default: two four-wave workgroups of 32 tiles x 64 channels per CU) and one wave's loads, transform
+// VALU and barrier waits run under the other's MFMAs.  Operands stream global -> LDS directly (buffer_load ... lds) in 64-deep K slabs
 // of 32 KB through a 3-deep ring, one s_barrier per slab.
 // Tried first and dropped (round 2, measured): 32 tiles x 32 channels per wave on v_mfma_f32_32x32x2_f32 -- 256 Y registers,
 // hence ONE wave per SIMD, and an in-order wave alone on its SIMD exposes every instruction that is not an MFMA: matrix pipes
@@ -41,10 +41,12 @@ struct WinoFusedParams {
 __device__ constexpr float kAt[4][6] = {{1, 1, 1, 1, 1, 0}, {0, 1, -1, 2, -2, 0}, {0, 1, 1, 4, 4, 0}, {0, 1, -1, 8, -8, 1}};
 static constexpr float kAtHost[4][6] = {{1, 1, 1, 1, 1, 0}, {0, 1, -1, 2, -2, 0}, {0, 1, 1, 4, 4, 0}, {0, 1, -1, 8, -8, 1}};
 
-template <int NBUF>
-__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
+template <int NBUF, int WGM>
+__global__ void __launch_bounds__(WGM * 128) __attribute__((amdgpu_waves_per_eu(2, 2)))
 wino_fused_kernel(const WinoFusedParams p) {
-    constexpr int NW = 8, BM = 64, BN = 64, KS = 64;
+    // WGM = 4: eight waves, 64 tiles x 64 channels, one workgroup per CU; WGM = 2: four waves, 32 tiles x 64 channels, two
+    // independent workgroups per CU (no common barrier between the two waves of a SIMD)
+    constexpr int NW = 2 * WGM, BM = 16 * WGM, BN = 64, KS = 64;
     constexpr int ROWS = BM + BN;
     constexpr int NIA = BM / (4 * NW), NIB = BN / (4 * NW);   // 2 + 2 pieces of 1 KB (4 rows) per wave per slab
     constexpr int NL = NIA + NIB;
@@ -58,6 +60,7 @@ wino_fused_kernel(const WinoFusedParams p) {
     const int logical = xcd_contiguous(blockIdx.x, gridDim.x);
     const int tile_m = logical / p.tiles_n, tile_n = logical - tile_m * p.tiles_n;
     const int m_base = tile_m * BM, n_base = tile_n * BN;
+    static_assert(BM % (4 * NW) == 0 && BN % (4 * NW) == 0, "whole 1 KB pieces per wave");
     const int K = p.K, kslabs = K / KS;
 
     // ---- DMA (as wino_fused.hip): slot s of slab row r holds k-quad s ^ (r & 15); rows past the plane read as zeros
@@ -261,28 +264,29 @@ wino_fused_kernel(const WinoFusedParams p) {
     }
 }
 
-template <int NBUF>
+template <int NBUF, int WGM>
 static int launch_fused(WinoFusedParams p, hipStream_t s) {
-    constexpr int LDS_BYTES = NBUF * 128 * 64 * 4;
+    constexpr int BM = 16 * WGM;
+    constexpr int LDS_BYTES = NBUF * (BM + 64) * 64 * 4;
     static bool attr_set[16] = {};
     int dev = 0;
     (void)hipGetDevice(&dev);
     if (dev >= 0 && dev < 16 && !attr_set[dev]) {
-        MM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(wino_fused_kernel<NBUF>), hipFuncAttributeMaxDynamicSharedMemorySize,
+        MM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(wino_fused_kernel<NBUF, WGM>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                    LDS_BYTES));
         attr_set[dev] = true;
     }
     p.tiles_n = (p.Cout + 63) / 64;
     for (int q = 0; q < 6; ++q)
         for (int qq = 0; qq < 4; ++qq) p.at_cols[q * 4 + qq] = kAtHost[qq][q];
-    const int64_t blocks = (int64_t)((p.ntile + 63) / 64) * p.tiles_n;
+    const int64_t blocks = (int64_t)((p.ntile + BM - 1) / BM) * p.tiles_n;
     if (blocks <= 0 || blocks > 0x7fffffff) return MM_ERR_INVALID_ARG;
     if (prof_enabled()) {
         char tag[64];
-        snprintf(tag, sizeof(tag), "wino-fused M=%d K=%d N=%d t64x64 b36", p.ntile, p.K, p.Cout);
+        snprintf(tag, sizeof(tag), "wino-fused M=%d K=%d N=%d t%dx64 b36", p.ntile, p.K, p.Cout, BM);
         prof_before(0, 2.0 * 36.0 * (double)p.ntile * (double)p.K * (double)p.Cout, s, tag);
     }
-    hipLaunchKernelGGL((wino_fused_kernel<NBUF>), dim3((unsigned)blocks), dim3(512), LDS_BYTES, s, p);
+    hipLaunchKernelGGL((wino_fused_kernel<NBUF, WGM>), dim3((unsigned)blocks), dim3(WGM * 128), LDS_BYTES, s, p);
     prof_after(0, s);
     MM_LAUNCH_CHECK();
     return MM_OK;
@@ -290,7 +294,7 @@ static int launch_fused(WinoFusedParams p, hipStream_t s) {
 
 // V [36][ntile][Cin] (from wino_input_transform, m = 4), U [36][Cout][Cin] -> y NHWC [B,H,W,Cout] (+bias, ReLU)
 int wino_gemm_output_fused(const float* V, const float* U, const float* bias, float* y, int B, int H, int W, int Cin, int Cout,
-                            int relu, int ring, hipStream_t s) {
+                            int relu, int shape, hipStream_t s) {
     if (Cin % 64 || Cout % 32) return MM_ERR_UNSUPPORTED;
     WinoFusedParams p;
     p.V = V; p.U = U; p.bias = bias; p.out = y;
@@ -299,7 +303,10 @@ int wino_gemm_output_fused(const float* V, const float* U, const float* bias, fl
     if (ntile <= 0) return MM_OK;
     if ((ntile + 64) * Cin * 4 >= 0xFFFFF000ll || ((int64_t)Cout + 64) * Cin * 4 >= 0xFFFFF000ll) return MM_ERR_INVALID_ARG;
     p.ntile = (int)ntile; p.K = Cin; p.Cout = Cout; p.B = B; p.H = H; p.W = W; p.relu = relu; p.tiles_n = 0;
-    return ring == 4 ? launch_fused<4>(p, s) : launch_fused<3>(p, s);   // depth of the slab ring
+    // shape: 0 = four-wave workgroups of 32 tiles x 64 channels, two per CU (default: measured 3-6 % faster than one eight-wave
+    // workgroup per CU -- no common barrier between the two waves of a SIMD, prologue / epilogue of one workgroup under the
+    // other's main loop); 8 = eight waves (64 x 64), 3-deep ring; 4 = eight waves, 4-deep ring
+    return shape == 4 ? launch_fused<4, 4>(p, s) : shape == 8 ? launch_fused<3, 4>(p, s) : launch_fused<3, 2>(p, s);
 }
 
 }  // namespace mm
