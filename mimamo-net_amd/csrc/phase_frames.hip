@@ -135,16 +135,22 @@ phase_frame_kernel(const float* __restrict__ polar, int64_t img_stride, int64_t 
     }
 }
 
-// ---- per (window, band): 12 phase-difference planes from the frame planes
+// ---- per (window, band): 12 phase-difference planes from the frame planes.  The 13 frames of a window are independent once the
+//      wrap counts are known (a running sum in registers), so F frames go through each barrier round together: 3 barriers per
+//      round instead of per frame, F times the work between them.
+#ifndef MM_PHASE_FPR
+#define MM_PHASE_FPR 3      // frames per barrier round
+#endif
 template <int W>
 __global__ void __launch_bounds__(Cfg<W>::NTHREADS)
 phase_window2_kernel(const float* __restrict__ fr, const int32_t* __restrict__ ids, float* __restrict__ out, int out_nhwc,
                      int out_cstride, int out_coffset) {
     using C = Cfg<W>;
-    __shared__ __attribute__((aligned(16))) float lds[C::IN_PLANE + C::TMP_PLANE + 64 * (P - 1)];
-    float* in_x = lds;
-    float* tmp_x = in_x + C::IN_PLANE;
-    float* red = tmp_x + C::TMP_PLANE;
+    constexpr int F = MM_PHASE_FPR;
+    __shared__ __attribute__((aligned(16))) float lds[F * (C::IN_PLANE + C::TMP_PLANE) + 64 * (P - 1)];
+    float* in_x = lds;                              // [F][IN_PLANE]
+    float* tmp_x = in_x + F * C::IN_PLANE;          // [F][TMP_PLANE]
+    float* red = tmp_x + F * C::TMP_PLANE;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // consecutive windows share 12 of their 13 frames: keep them on one XCD (one L2) instead of spreading them over all eight
     const int logical = xcd_contiguous(blockIdx.x, gridDim.x);
@@ -154,7 +160,7 @@ phase_window2_kernel(const float* __restrict__ fr, const int32_t* __restrict__ i
     const int y = active ? tid / C::STRIPS : 0;
     const int x0 = active ? (tid - y * C::STRIPS) * PX : 0;
     const int px = y * W + x0;
-    for (int i = tid; i < C::IN_PLANE + C::TMP_PLANE; i += C::NTHREADS) lds[i] = 0.f;
+    for (int i = tid; i < F * (C::IN_PLANE + C::TMP_PLANE); i += C::NTHREADS) lds[i] = 0.f;
     __syncthreads();
     const float PI_F = 3.14159265358979323846f, TWO_PI_F = 6.28318530717958647692f;
     float kacc[PX] = {0.f, 0.f, 0.f, 0.f}, prev_out[PX], d[P - 1][PX], part[P - 1];
@@ -162,48 +168,79 @@ phase_window2_kernel(const float* __restrict__ fr, const int32_t* __restrict__ i
     for (int k = 0; k < P - 1; ++k) part[k] = 0.f;
     int prev_id = -1;
 #pragma unroll
-    for (int i = 0; i < P; ++i) {
-        const int id = ids[j * P + i];
-        const float* o = fr + ((int64_t)id * 2 + band) * C::FRAME_FLOATS;
-        float4 b4 = {0.f, 0.f, 0.f, 0.f}, r4 = b4;
+    for (int base = 0; base < P; base += F) {
+        float4 b4[F], r4[F];
+        const float* fo[F];
         int nz = 0;
-        if (active) {
-            b4 = *reinterpret_cast<const float4*>(o + C::PLANE + px);
-            if (i > 0 && id != prev_id) {      // a new frame: its wrap flags refer to the frame before it, which is prev_id
-                const unsigned wb = reinterpret_cast<const unsigned*>(o + 3 * C::PLANE)[px / 4];
-                kacc[0] += (float)(wb & 1u); kacc[1] += (float)((wb >> 8) & 1u);
-                kacc[2] += (float)((wb >> 16) & 1u); kacc[3] += (float)((wb >> 24) & 1u);
+#pragma unroll
+        for (int f = 0; f < F; ++f) {
+            const int i = base + f;
+            b4[f] = r4[f] = float4{0.f, 0.f, 0.f, 0.f};
+            fo[f] = fr;
+            if (i >= P) continue;
+            const int id = ids[j * P + i];
+            const float* o = fr + ((int64_t)id * 2 + band) * C::FRAME_FLOATS;
+            fo[f] = o;
+            if (active) {
+                b4[f] = *reinterpret_cast<const float4*>(o + C::PLANE + px);
+                if (i > 0 && id != prev_id) {      // a new frame: its wrap flags refer to the frame before it, which is prev_id
+                    const unsigned wb = reinterpret_cast<const unsigned*>(o + 3 * C::PLANE)[px / 4];
+                    kacc[0] += (float)(wb & 1u); kacc[1] += (float)((wb >> 8) & 1u);
+                    kacc[2] += (float)((wb >> 16) & 1u); kacc[3] += (float)((wb >> 24) & 1u);
+                }
+                if ((kacc[0] + kacc[1] + kacc[2] + kacc[3]) != 0.f) {
+                    nz = 1;
+                    const float4 m4 = *reinterpret_cast<const float4*>(o + px);
+                    *reinterpret_cast<float4*>(in_x + f * C::IN_PLANE + px) =
+                        float4{m4.x * (-TWO_PI_F * kacc[0]), m4.y * (-TWO_PI_F * kacc[1]), m4.z * (-TWO_PI_F * kacc[2]),
+                               m4.w * (-TWO_PI_F * kacc[3])};
+                } else {
+                    *reinterpret_cast<float4*>(in_x + f * C::IN_PLANE + px) = float4{0.f, 0.f, 0.f, 0.f};
+                }
             }
-            nz = (kacc[0] + kacc[1] + kacc[2] + kacc[3]) != 0.f;
+            prev_id = id;
         }
-        prev_id = id;
-        float s[PX] = {0.f, 0.f, 0.f, 0.f};
-        // no pixel of this window has wrapped up to frame i: blur(mag * 0) = 0, the ratio is the frame's own B
+        float s[F][PX];
+#pragma unroll
+        for (int f = 0; f < F; ++f) s[f][0] = s[f][1] = s[f][2] = s[f][3] = 0.f;
+        // no pixel of this window has wrapped up to the last frame of the round: blur(mag * 0) = 0, the ratios are the frames' own B
         if (__syncthreads_or(nz)) {
             if (active) {
-                const float4 m4 = *reinterpret_cast<const float4*>(o + px);
-                r4 = *reinterpret_cast<const float4*>(o + 2 * C::PLANE + px);
-                *reinterpret_cast<float4*>(in_x + px) = float4{m4.x * (-TWO_PI_F * kacc[0]), m4.y * (-TWO_PI_F * kacc[1]),
-                                                               m4.z * (-TWO_PI_F * kacc[2]), m4.w * (-TWO_PI_F * kacc[3])};
+#pragma unroll
+                for (int f = 0; f < F; ++f) {
+                    if (base + f >= P) continue;
+                    r4[f] = *reinterpret_cast<const float4*>(fo[f] + 2 * C::PLANE + px);   // a pixel's blur also sums its neighbours' wraps
+                    float h[PX];
+                    row_pass<W>(in_x + f * C::IN_PLANE, y, x0, h);
+                    *reinterpret_cast<float4*>(tmp_x + f * C::TMP_PLANE + (y + R) * W + x0) = float4{h[0], h[1], h[2], h[3]};
+                }
             }
             __syncthreads();
             if (active) {
-                float h[PX];
-                row_pass<W>(in_x, y, x0, h);
-                *reinterpret_cast<float4*>(tmp_x + (y + R) * W + x0) = float4{h[0], h[1], h[2], h[3]};
+#pragma unroll
+                for (int f = 0; f < F; ++f) {
+                    if (base + f >= P) continue;
+                    col_pass<W>(tmp_x + f * C::TMP_PLANE, y, x0, s[f]);
+                }
             }
-            __syncthreads();
-            if (active) col_pass<W>(tmp_x, y, x0, s);
+            // (the next round's in_x stores are separated from this round's row-pass reads by the barrier above, its tmp_x stores
+            //  from these column reads by its own __syncthreads_or)
         }
         if (active) {
-            const float o4[PX] = {fmaf(s[0], r4.x, b4.x), fmaf(s[1], r4.y, b4.y), fmaf(s[2], r4.z, b4.z), fmaf(s[3], r4.w, b4.w)};
 #pragma unroll
-            for (int p = 0; p < PX; ++p) {
-                if (i > 0) {
-                    d[i - 1][p] = o4[p] - prev_out[p];
-                    part[i - 1] += d[i - 1][p];
+            for (int f = 0; f < F; ++f) {
+                const int i = base + f;
+                if (i >= P) continue;
+                const float o4[PX] = {fmaf(s[f][0], r4[f].x, b4[f].x), fmaf(s[f][1], r4[f].y, b4[f].y), fmaf(s[f][2], r4[f].z, b4[f].z),
+                                      fmaf(s[f][3], r4[f].w, b4[f].w)};
+#pragma unroll
+                for (int p = 0; p < PX; ++p) {
+                    if (i > 0) {
+                        d[i - 1][p] = o4[p] - prev_out[p];
+                        part[i - 1] += d[i - 1][p];
+                    }
+                    prev_out[p] = o4[p];
                 }
-                prev_out[p] = o4[p];
             }
         }
     }
