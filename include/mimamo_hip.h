@@ -189,8 +189,9 @@ int mm_resnet50_destroy(mm_resnet50_t* h);
  * the layers with <= 256 input channels (conv2_x..conv4_x), variant 4 for conv5_x. */
 int mm_resnet50_set_winograd(mm_resnet50_t* h, int enable);
 int64_t mm_resnet50_workspace_bytes(mm_resnet50_t* h, int64_t batch);
-/* images: device f32, [batch,3,224,224] (nchw=1, the reference's layout) or channels-last padded to four
- * channels [batch,224,224,4] (nchw=0; the 4th channel is ignored);
+/* images: device f32, [batch,3,224,224] (nchw=1, the reference's layout), channels-last padded to four
+ * channels [batch,224,224,4] (nchw=0; the 4th channel is ignored) or zero-bordered packed rows [batch,230,230,3]
+ * (nchw=2, what mm_preproc_forward writes with rgb_nchw=2: the 7x7/2 stem then runs with K = 168 instead of 196);
  * already normalised (255*x - mean, api/utils/model_utils.py:36-39).  out: [batch, 2048]
  * = relu(pool5_7x7_s1) on the device (the reference copies it to a CPU tensor and squeeze()s
  * it -- quirk Q8, not reproduced). */
@@ -235,8 +236,9 @@ int mm_preproc_host_coeffs(int in_size, int out_size, int filter, int* ksize, in
 int mm_preproc_create(mm_preproc_t** out, int in_size, int gray_size, int resize, int crop, const float* mean3);
 int mm_preproc_destroy(mm_preproc_t* h);
 /* frames: device uint8 [n, in_size, in_size, 3] (RGB, the BMP pixel order).  gray_out: f32 [n,gray,gray] in [0,1];
- * rgb_out: f32 [n,3,crop,crop] (rgb_nchw=1) or channels-last padded [n,crop,crop,4] (rgb_nchw=0), 255*x - mean.
- * Either output may be NULL. */
+ * rgb_out: f32 [n,3,crop,crop] (rgb_nchw=1), channels-last padded to four channels [n,crop,crop,4] (rgb_nchw=0) or packed
+ * three-channel rows with the stem's 3-pixel zero border in memory [n,crop+6,crop+6,3] (rgb_nchw=2: input mode 2 of
+ * mm_resnet50_forward), 255*x - mean.  Either output may be NULL. */
 int mm_preproc_forward(mm_preproc_t* h, const uint8_t* frames, int64_t n, float* gray_out, float* rgb_out,
                        int rgb_nchw, void* stream);
 

@@ -17,7 +17,7 @@ struct ConvParams {
     int res_cstride, res_coff;
     int kh, kw, stride, pad;
     int K, Kpad;
-    int korder;      // 0: k=(r,s,c)   1: k=(c/16,r,s,c%16), needs Cin % 16 == 0 (see conv_mfma.hip)
+    int korder;      // 0: k=(r,s,c)   1: k=(c/16,r,s,c%16), needs Cin % 16 == 0   2: packed 3-channel rows (see conv_mfma.hip)
     int relu;
     int force_tile;  // 0 auto, 1 = 128x128, 2 = 128x64, 3 = 64x64, 4 = 256x64, 5 = 128x256 (8 waves, 1x1 only), 16+bits = ablation build
     int ablate;

@@ -45,6 +45,10 @@ constexpr int CLD = 16;   // LDS row = one 16-float chunk; the four 16-byte slot
 //   0  k = (r,s,c), any Cin % 4 == 0 (stem: Cin = 4)      2  k = (r,s,c), Cin >= 16 (one wrap per chunk at most)
 //   1  slice-major k = (c/16, r, s, c%16), Cin % 16 == 0    3  1x1 kernel, pad 0: no taps, no border
 //   4  Cin == 4 and kw >= 4 (the 7x7 stem on NHWC4): a k-quad is one tap, four taps per chunk
+//   5  3-channel input packed NHWC3 with its zero border IN MEMORY (korder 2, the stem): k = r * RG + s * 3 + c with the kw * 3
+//      floats of a kernel row padded to RG = a multiple of 4 (7 x 3 = 21 -> 24: K = 168 instead of 7 * 7 * 4 = 196 -> 208); a
+//      k-quad is 4 consecutive floats of the input row -- 4-byte aligned only, which the LDS-DMA accepts (tools/probes/unaligned_dma.hip)
+//      -- and the three floats past a row group meet zero weights.  No border logic: pad must be 0.
 template <int BM, int BN, int WGM, int WGN, int KMODE, bool ABL = false>
 __global__ void __launch_bounds__(WGM * WGN * 64)
 conv_mfma_kernel(const ConvParams p) {
@@ -134,7 +138,12 @@ conv_mfma_kernel(const ConvParams p) {
     //              chunks and is served by L1/L2 instead of the fabric (measured: conv4_x 3x3 fetched 8.5x its
     //              input with korder 0).
     int tk = kq * 4, tr, ts, tc;
-    if (KMODE != 1) {
+    const int rgq = KMODE == 5 ? (p.kw * 3 + 3) / 4 : 1;   // k-quads per kernel row (KMODE 5)
+    if (KMODE == 5) {
+        tr = kq / rgq;
+        ts = kq - tr * rgq;      // quad inside the row group
+        tc = 0;
+    } else if (KMODE != 1) {
         const int rs = tk / p.Cin;
         tc = tk - rs * p.Cin;
         tr = rs / p.kw;
@@ -147,6 +156,12 @@ conv_mfma_kernel(const ConvParams p) {
     unsigned va[AIT];
     auto tap_offsets = [&]() {
         const bool kok = tk < p.K;
+        if (KMODE == 5) {
+            const int tapoff = tr * p.W * 3 + ts * 4;
+#pragma unroll
+            for (int it = 0; it < AIT; ++it) va[it] = (kok && a_ok[it]) ? (unsigned)(a_pix[it] + tapoff) * 4u : OOB;
+            return;
+        }
         if (KMODE == 3) {
 #pragma unroll
             for (int it = 0; it < AIT; ++it) va[it] = (kok && a_ok[it]) ? (unsigned)(a_pix[it] + tk) * 4u : OOB;
@@ -182,6 +197,9 @@ conv_mfma_kernel(const ConvParams p) {
         } else if (KMODE == 4) {
             ts += CBK / 4;
             if (ts >= p.kw) { ts -= p.kw; ++tr; }
+        } else if (KMODE == 5) {
+            ts += CBK / 4;
+            while (ts >= rgq) { ts -= rgq; ++tr; }
         }
 #pragma unroll
         for (int it = 0; it < BIT; ++it) vb[it] = vb[it] == OOB ? OOB : vb[it] + CBK * 4u;
@@ -404,6 +422,7 @@ static int launch_km(ConvParams p, hipStream_t stream) {
 
 template <int BM, int BN, int WGM, int WGN>
 static int launch_cfg(const ConvParams& p, hipStream_t stream) {
+    if (p.korder == 2) return launch_km<BM, BN, WGM, WGN, 5>(p, stream);
     if (p.kh == 1 && p.kw == 1 && p.pad == 0) return launch_km<BM, BN, WGM, WGN, 3>(p, stream);
     if (p.korder == 1) return launch_km<BM, BN, WGM, WGN, 1>(p, stream);
     if (p.Cin >= CBK) return launch_km<BM, BN, WGM, WGN, 2>(p, stream);
@@ -413,8 +432,14 @@ static int launch_cfg(const ConvParams& p, hipStream_t stream) {
 
 int conv_forward(const ConvParams& p0, hipStream_t stream) {
     ConvParams p = p0;
-    if (p.Cin % 4 || p.in_cstride % 4 || p.in_coff % 4 || p.Kpad % CBK || p.K > p.Kpad) return MM_ERR_INVALID_ARG;
-    if (p.korder != 0 && (p.korder != 1 || p.Cin % CBK)) return MM_ERR_INVALID_ARG;
+    if (p.korder == 2) {   // packed 3-channel input, zero border in memory (KMODE 5)
+        if (p.Cin != 3 || p.in_cstride != 3 || p.in_coff != 0 || p.pad != 0 || p.K != p.kh * ((p.kw * 3 + 3) / 4) * 4 || p.Kpad % CBK ||
+            p.K > p.Kpad)
+            return MM_ERR_INVALID_ARG;
+    } else {
+        if (p.Cin % 4 || p.in_cstride % 4 || p.in_coff % 4 || p.Kpad % CBK || p.K > p.Kpad) return MM_ERR_INVALID_ARG;
+        if (p.korder != 0 && (p.korder != 1 || p.Cin % CBK)) return MM_ERR_INVALID_ARG;
+    }
     // 32-bit byte offsets inside the kernel: the weight matrix, and the few images one block spans (the A descriptor is rebased to
     // the block's first image; the largest block tile is 256 rows -- force_tile 4)
     if ((uint64_t)p.Cout * p.Kpad * 4 >= 0xFFFFF000ull) return MM_ERR_INVALID_ARG;

@@ -48,7 +48,31 @@ struct BN {
 // Build one conv/linear layer from host tensors.  w: [cout][cin][k][k] (OIHW), bias may be null.
 // fold: BN directly after the conv (scale into the weights).  post: BN after the ReLU.
 static int make_layer(DeviceArena& A, Layer& L, const float* w, const float* bias, int cout, int cin, int k, int stride,
-                      int pad, int relu, const BN* fold, const BN* post, float eps, bool wino = false) {
+                      int pad, int relu, const BN* fold, const BN* post, float eps, bool wino = false, bool packed3 = false) {
+    if (packed3) {
+        // 3-channel input rows packed NHWC3 with the zero border in memory (conv_mfma.hip KMODE 5): k = r * RG + s * 3 + c, RG = the
+        // k * 3 floats of a kernel row rounded up to a multiple of 4 (zero weights in the slack)
+        if (cin != 3) return MM_ERR_INVALID_ARG;
+        const int RG = (k * 3 + 3) / 4 * 4;
+        L.cin = 3; L.cin_p = 3; L.cout = cout; L.k = k; L.stride = stride; L.pad = 0; L.relu = relu;
+        L.K = k * RG; L.Kpad = (L.K + 15) / 16 * 16; L.korder = 2;
+        std::vector<float> hw((size_t)cout * L.Kpad, 0.f), hb(cout, 0.f);
+        for (int o = 0; o < cout; ++o) {
+            double sc = 1.0, sh = 0.0;
+            if (fold) {
+                sc = (double)fold->gamma[o] / std::sqrt((double)fold->var[o] + (double)eps);
+                sh = (double)fold->beta[o] - (double)fold->mean[o] * sc;
+            }
+            for (int c = 0; c < 3; ++c)
+                for (int r = 0; r < k; ++r)
+                    for (int q = 0; q < k; ++q)
+                        hw[(size_t)o * L.Kpad + r * RG + q * 3 + c] = (float)((double)w[(((size_t)o * 3 + c) * k + r) * k + q] * sc);
+            hb[o] = (float)((bias ? (double)bias[o] : 0.0) * sc + sh);
+        }
+        int rc = A.upload(hw, &L.w);
+        if (rc == MM_OK) rc = A.upload(hb, &L.bias);
+        return rc;
+    }
     L.cin = cin;
     L.cin_p = (cin + 3) / 4 * 4;
     L.cout = cout;
@@ -200,7 +224,8 @@ struct Bottleneck {
 
 struct mm_resnet50 {
     mm::DeviceArena arena;
-    mm::Layer stem;
+    mm::Layer stem;    // 7x7/2 on NHWC4 input (K = 196 -> 208)
+    mm::Layer stem3;   // the same layer on zero-bordered NHWC3 input (K = 168 -> 176): input mode 2 of mm_resnet50_forward
     std::vector<mm::Bottleneck> blocks;
     int ceil_mode;
     int winograd;  // 0 direct, 2 = F(2x2,3x3), 4 = F(4x4,3x3) for the layers that have Winograd-domain weights
@@ -311,6 +336,11 @@ int mm_resnet50_create(mm_resnet50_t** out, const float* blob, int64_t n_floats,
         p += 4 * cout;
         if (rc == MM_OK) rc = make_layer(h->arena, L, w, nullptr, cout, cin, k, stride, pad, relu, &bn, nullptr, bn_eps, true);
     };
+    {   // both stem forms share the blob entry
+        const float* w = p;
+        BN bn{p + 64 * 3 * 49, p + 64 * 3 * 49 + 64, p + 64 * 3 * 49 + 128, p + 64 * 3 * 49 + 192};
+        rc = make_layer(h->arena, h->stem3, w, nullptr, 64, 3, 7, 2, 0, 1, &bn, nullptr, bn_eps, false, true);
+    }
     conv_bn(h->stem, 64, 3, 7, 2, 3, 1);
     int cin = 64;
     for (auto& st : kStages)
@@ -379,14 +409,20 @@ int mm_resnet50_forward(mm_resnet50_t* h, const float* images, int nchw, int64_t
     float* wm = ws.take(batch * kRsWino);  // Winograd M
     int rc;
     const float* x0 = images;
-    if (nchw) {
-        rc = nchw_to_nhwc(images, in4, batch, 3, 224 * 224, 4, 0, 4, s);
-        if (rc != MM_OK) return rc;
-        x0 = in4;
-    }
     int H = 224, W = 224, Ho, Wo;
-    rc = run_layer(h->stem, x0, B, H, W, 4, 0, big[0], 64, 0, nullptr, 0, s, &Ho, &Wo);
+    if (nchw == 2) {
+        // zero-bordered NHWC3 [batch, 230, 230, 3] (mm_preproc_forward layout 2): no layout conversion, K = 168 stem
+        rc = run_layer(h->stem3, x0, B, 230, 230, 3, 0, big[0], 64, 0, nullptr, 0, s, &Ho, &Wo);
+    } else {
+        if (nchw) {
+            rc = nchw_to_nhwc(images, in4, batch, 3, 224 * 224, 4, 0, 4, s);
+            if (rc != MM_OK) return rc;
+            x0 = in4;
+        }
+        rc = run_layer(h->stem, x0, B, H, W, 4, 0, big[0], 64, 0, nullptr, 0, s, &Ho, &Wo);
+    }
     if (rc != MM_OK) return rc;
+    if (Ho != 112 || Wo != 112) return MM_ERR_UNSUPPORTED;
     H = Ho; W = Wo;
     // MaxPool2d(3, 2, pad 0, ceil_mode)
     if (h->ceil_mode) {

@@ -131,6 +131,20 @@ preproc_rgb_kernel(const uint8_t* __restrict__ frames, int S, int R, int C, int 
     const int off = (int)rintf((R - C) / 2.0f);  // CenterCrop: int(round((256-224)/2.)) = 16
     const uint8_t* src = frames + n * (int64_t)S * S * 3;
     const float mean[3] = {mean0, mean1, mean2};
+    if (nchw == 2) {
+        // the 3-pixel zero border of this block's 16 rows (left / right), and the three full rows above / below by the first / last block
+        const int CP = C + 6;
+        float* img = out + n * (int64_t)CP * CP * 3;
+        for (int i = threadIdx.x; i < 16 * 18; i += 256) {
+            const int ry = i / 18, e = i - ry * 18;
+            const int oy = row0 + ry;
+            if (oy < C) img[((int64_t)(oy + 3) * CP + (e < 9 ? 0 : C + 3)) * 3 + (e < 9 ? e : e - 9)] = 0.f;
+        }
+        if (blockIdx.y == 0)
+            for (int i = threadIdx.x; i < 3 * CP * 3; i += 256) img[i] = 0.f;
+        if (blockIdx.y == gridDim.y - 1)
+            for (int i = threadIdx.x; i < 3 * CP * 3; i += 256) img[(int64_t)(C + 3) * CP * 3 + i] = 0.f;
+    }
     for (int i = threadIdx.x; i < 16 * C; i += 256) {
         const int ry = i / C, cx = i - ry * C;
         const int oy = row0 + ry;
@@ -169,7 +183,14 @@ preproc_rgb_kernel(const uint8_t* __restrict__ frames, int S, int R, int C, int 
                 v[c] = m255 - mean[c];
             }
         }
-        if (nchw) {
+        if (nchw == 2) {
+            // zero-bordered packed NHWC3 [n][C + 6][C + 6][3]: the stem's padding lives in memory (conv_mfma.hip KMODE 5)
+            const int CP = C + 6;
+            float* o = out + ((n * CP + oy + 3) * (int64_t)CP + cx + 3) * 3;
+            o[0] = v[0];
+            o[1] = v[1];
+            o[2] = v[2];
+        } else if (nchw) {
             float* o = out + n * 3 * (int64_t)C * C + (int64_t)oy * C + cx;
             o[0] = v[0];
             o[(int64_t)C * C] = v[1];

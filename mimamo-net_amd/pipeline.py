@@ -115,16 +115,16 @@ class HotPath(object):
             self._pre = FramePreprocessor(device=self.device)
         N, step = frames_u8.shape[0], self.max_frames_per_call
         if N <= step:
-            gray, rgb4 = self._pre(frames_u8, channels_last4=True)
-            feats = self.resnet.get_vec(rgb4, channels_last4=True)
+            gray, rgb3 = self._pre(frames_u8, bordered3=True)
+            feats = self.resnet.get_vec(rgb3)
         else:
             gray = torch.empty((N, self._pre.phase_size, self._pre.phase_size), dtype=torch.float32, device=frames_u8.device)
             feats = torch.empty((N, 2048), dtype=torch.float32, device=frames_u8.device)
             for c0 in range(0, N, step):
                 c1 = min(N, c0 + step)
-                g, rgb4 = self._pre(frames_u8[c0:c1], channels_last4=True)
+                g, rgb3 = self._pre(frames_u8[c0:c1], bordered3=True)
                 gray[c0:c1] = g
-                self.resnet.get_vec(rgb4, channels_last4=True, out=feats[c0:c1])
+                self.resnet.get_vec(rgb3, out=feats[c0:c1])
         return self._rows(gray, feats, plan)
 
     def _check(self, plan, n_frames, independent_clips):

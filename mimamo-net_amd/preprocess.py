@@ -31,8 +31,10 @@ class FramePreprocessor(object):
         except Exception:
             pass
 
-    def __call__(self, frames_u8, channels_last4=True, want_gray=True, want_rgb=True):
-        """frames_u8: uint8 device tensor [n,S,S,3].  Returns (gray [n,48,48] or None, rgb or None)."""
+    def __call__(self, frames_u8, channels_last4=True, want_gray=True, want_rgb=True, bordered3=False):
+        """frames_u8: uint8 device tensor [n,S,S,3].  Returns (gray [n,48,48] or None, rgb or None).
+        rgb layout: [n,3,crop,crop] (channels_last4=False), [n,crop,crop,4] (channels_last4=True) or, with bordered3=True, packed
+        three-channel rows with the stem's zero border in memory [n,crop+6,crop+6,3] (Resnet50_Extractor's fastest input)."""
         if not frames_u8.is_cuda or frames_u8.dtype != torch.uint8:
             raise RuntimeError("frames must be a uint8 tensor on the ROCm device")
         n = frames_u8.shape[0]
@@ -40,11 +42,12 @@ class FramePreprocessor(object):
         frames_u8 = frames_u8.contiguous()
         gray = torch.empty((n, self.phase_size, self.phase_size), dtype=torch.float32, device=frames_u8.device) if want_gray else None
         if want_rgb:
-            shape = (n, self.crop, self.crop, 4) if channels_last4 else (n, 3, self.crop, self.crop)
+            shape = ((n, self.crop + 6, self.crop + 6, 3) if bordered3 else
+                     (n, self.crop, self.crop, 4) if channels_last4 else (n, 3, self.crop, self.crop))
             rgb = torch.empty(shape, dtype=torch.float32, device=frames_u8.device)
         else:
             rgb = None
         rc = _lib.lib().mm_preproc_forward(self._handle, _lib.ptr(frames_u8), n, _lib.ptr(gray), _lib.ptr(rgb),
-                                           0 if channels_last4 else 1, _lib.current_stream())
+                                           2 if bordered3 else 0 if channels_last4 else 1, _lib.current_stream())
         _lib.check(rc, "mm_preproc_forward")
         return gray, rgb

@@ -83,13 +83,18 @@ class Resnet50_Extractor(object):
         """image [bs,3,224,224] (255*x - mean) -> pool5 features [bs,2048] ON THE DEVICE.
 
         (api/resnet50_extractor.py:74-83 returns relu(squeeze()) of a CPU copy; squeeze() collapsing bs=1 and
-        the host copy are quirk Q8 and are not reproduced.)  channels_last4=True takes [bs,224,224,4].
+        the host copy are quirk Q8 and are not reproduced.)  channels_last4=True takes [bs,224,224,4]; a [bs,230,230,3] tensor is
+        the zero-bordered packed layout FramePreprocessor(bordered3=True) writes.
         out: optional preallocated [bs,2048] fp32 device tensor (contiguous rows) the features are written to."""
         if not image.is_cuda:
             raise RuntimeError("image must be on the ROCm device; this build has no CPU path")
         assert image.dtype == torch.float32
         bs = image.size(0)
-        assert tuple(image.shape[1:]) == ((224, 224, 4) if channels_last4 else (3, 224, 224))
+        if tuple(image.shape[1:]) == (230, 230, 3):
+            mode = 2      # zero-bordered packed NHWC3 (FramePreprocessor(bordered3=True)): stem with K = 168
+        else:
+            assert tuple(image.shape[1:]) == ((224, 224, 4) if channels_last4 else (3, 224, 224))
+            mode = 0 if channels_last4 else 1
         image = image.contiguous()
         if out is None:
             out = torch.empty((bs, 2048), dtype=torch.float32, device=image.device)
@@ -99,7 +104,7 @@ class Resnet50_Extractor(object):
         ws, need = self._workspace(min(bs, step))
         for c0 in range(0, bs, step):
             c1 = min(bs, c0 + step)
-            rc = _lib.lib().mm_resnet50_forward(self._handle, _lib.ptr(image[c0:c1]), 0 if channels_last4 else 1, c1 - c0,
+            rc = _lib.lib().mm_resnet50_forward(self._handle, _lib.ptr(image[c0:c1]), mode, c1 - c0,
                                                 _lib.ptr(out[c0:c1]), _lib.ptr(ws), need, _lib.current_stream())
             _lib.check(rc, "mm_resnet50_forward")
         return out

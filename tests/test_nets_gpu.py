@@ -420,3 +420,24 @@ def test_head_mlp_hidden_units_variants(oracle, dev, units):
         Two_Stream_RNN(mlp_hidden_units=[2048, 128])          # the reference asserts hidden_units[-1] == 256
     with pytest.raises(RuntimeError, match="Missing key"):
         Two_Stream_RNN(mlp_hidden_units=units + [256]).load_state_dict(sd)
+
+
+def test_resnet50_input_layouts_agree(resnet, oracle, dev):
+    """The three input layouts of mm_resnet50_forward -- NCHW (the reference's), NHWC4, zero-bordered packed NHWC3 (stem with K = 168
+    instead of 196: a different summation order in the first layer only) -- give the same pool5 features."""
+    x = _images(3, 11)
+    want = oracle.resnet50_pool5(weights.make_resnet50_state_dict(seed=0), x)
+    xt = torch.from_numpy(x).to(dev)
+    a = resnet.get_vec(xt)
+    x4 = torch.zeros(3, 224, 224, 4, device=dev)
+    x4[..., :3] = xt.permute(0, 2, 3, 1)
+    b = resnet.get_vec(x4, channels_last4=True)
+    x3 = torch.zeros(3, 230, 230, 3, device=dev)
+    x3[:, 3:227, 3:227, :] = xt.permute(0, 2, 3, 1)
+    c = resnet.get_vec(x3)
+    assert torch.equal(a, b)
+    scale = np.abs(want).max()
+    for got in (a, c):
+        g = got.cpu().numpy()
+        assert np.abs(g - want).max() / scale < POOL5_RTOL * 10 and np.abs(g - want).mean() / scale < POOL5_RTOL
+    assert (a - c).abs().max().item() / scale < 1e-5

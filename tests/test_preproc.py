@@ -72,5 +72,15 @@ def test_gpu_preprocessing_bit_exact_with_pil(pkg):
     assert (r4[..., 3] == 0).all()
     _, r = pp(torch.from_numpy(frames).to(dev), channels_last4=False, want_gray=False)
     np.testing.assert_array_equal(r.cpu().numpy(), rgb_ref)
+    # zero-bordered packed three-channel layout (the stem's padding in memory): same values inside, exact zeros around
+    stale = torch.full((frames.shape[0], 230, 230, 3), 7.0, device=dev)     # the kernel must write the border itself
+    del stale
+    _, r3 = pp(torch.from_numpy(frames).to(dev), bordered3=True, want_gray=False)
+    r3 = r3.cpu().numpy()
+    assert r3.shape == (frames.shape[0], 230, 230, 3)
+    np.testing.assert_array_equal(r3[:, 3:227, 3:227, :].transpose(0, 3, 1, 2), rgb_ref)
+    border = r3.copy()
+    border[:, 3:227, 3:227, :] = 0
+    assert (border == 0).all()
     with pytest.raises(RuntimeError):
         pp(torch.from_numpy(frames))
