@@ -31,6 +31,8 @@ int conv_forward(const ConvParams& p, hipStream_t stream);
 
 // NCHW [N,C,HW] -> NHWC [N,HW,cstride] at channel offset coff; channels [C, cpad) are zero-filled
 int nchw_to_nhwc(const float* in, float* out, int64_t N, int C, int HW, int cstride, int coff, int cpad, hipStream_t s);
+// NCHW [N,3,S,S] -> zero-bordered packed NHWC3 [N,S+2pad,S+2pad,3]
+int nchw3_to_bordered_nhwc3(const float* in, float* out, int64_t N, int S, int pad, hipStream_t s);
 // MaxPool2d(k=3, s=2, pad=0, ceil_mode) on NHWC
 int maxpool3x3s2(const float* in, float* out, int64_t N, int H, int W, int C, int Ho, int Wo, hipStream_t s);
 // global average pool over HW (AvgPool2d(k=HW side)); optional ReLU afterwards

@@ -33,6 +33,33 @@ nchw3_to_nhwc4_kernel(const float* __restrict__ in, float4* __restrict__ out, in
     out[i] = float4{p[0], p[HW], p[2 * (int64_t)HW], 0.f};
 }
 
+// 3-channel planes [N,3,S,S] -> packed channels-last rows with a zero border of `pad` pixels [N,S+2pad,S+2pad,3] (the stem's input
+// layout, conv_mfma.hip KMODE 5): one thread per output pixel, three coalesced plane reads
+__global__ void __launch_bounds__(256)
+nchw3_to_bordered_nhwc3_kernel(const float* __restrict__ in, float* __restrict__ out, int64_t total, int S, int pad) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int SP = S + 2 * pad;
+    const int64_t n = i / ((int64_t)SP * SP);
+    const int rem = (int)(i - n * (int64_t)SP * SP);
+    const int y = rem / SP - pad, x = rem - (rem / SP) * SP - pad;
+    float v0 = 0.f, v1 = 0.f, v2 = 0.f;
+    if ((unsigned)y < (unsigned)S && (unsigned)x < (unsigned)S) {
+        const float* p = in + (n * 3 * S + y) * (int64_t)S + x;
+        v0 = p[0]; v1 = p[(int64_t)S * S]; v2 = p[2 * (int64_t)S * S];
+    }
+    float* o = out + i * 3;
+    o[0] = v0; o[1] = v1; o[2] = v2;
+}
+
+int nchw3_to_bordered_nhwc3(const float* in, float* out, int64_t N, int S, int pad, hipStream_t s) {
+    if (N <= 0) return MM_OK;
+    const int64_t total = N * (int64_t)(S + 2 * pad) * (S + 2 * pad);
+    hipLaunchKernelGGL(nchw3_to_bordered_nhwc3_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, in, out, total, S, pad);
+    MM_LAUNCH_CHECK();
+    return MM_OK;
+}
+
 int nchw_to_nhwc(const float* in, float* out, int64_t N, int C, int HW, int cstride, int coff, int cpad, hipStream_t s) {
     if (N <= 0) return MM_OK;
     if (cpad < C) cpad = C;

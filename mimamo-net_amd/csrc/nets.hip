@@ -410,16 +410,17 @@ int mm_resnet50_forward(mm_resnet50_t* h, const float* images, int nchw, int64_t
     int rc;
     const float* x0 = images;
     int H = 224, W = 224, Ho, Wo;
-    if (nchw == 2) {
-        // zero-bordered NHWC3 [batch, 230, 230, 3] (mm_preproc_forward layout 2): no layout conversion, K = 168 stem
-        rc = run_layer(h->stem3, x0, B, 230, 230, 3, 0, big[0], 64, 0, nullptr, 0, s, &Ho, &Wo);
-    } else {
-        if (nchw) {
-            rc = nchw_to_nhwc(images, in4, batch, 3, 224 * 224, 4, 0, 4, s);
+    if (nchw) {
+        // zero-bordered packed NHWC3 [batch, 230, 230, 3]: handed over (2, mm_preproc_forward layout 2) or converted from the
+        // reference's NCHW (1) into the workspace (230 * 230 * 3 < 224 * 224 * 4 floats); stem with K = 168
+        if (nchw == 1) {
+            rc = nchw3_to_bordered_nhwc3(images, in4, batch, 224, 3, s);
             if (rc != MM_OK) return rc;
             x0 = in4;
         }
-        rc = run_layer(h->stem, x0, B, H, W, 4, 0, big[0], 64, 0, nullptr, 0, s, &Ho, &Wo);
+        rc = run_layer(h->stem3, x0, B, 230, 230, 3, 0, big[0], 64, 0, nullptr, 0, s, &Ho, &Wo);
+    } else {
+        rc = run_layer(h->stem, x0, B, H, W, 4, 0, big[0], 64, 0, nullptr, 0, s, &Ho, &Wo);   // NHWC4: K = 196
     }
     if (rc != MM_OK) return rc;
     if (Ho != 112 || Wo != 112) return MM_ERR_UNSUPPORTED;

@@ -228,7 +228,8 @@ def test_resnet50_pool5_vs_oracle(resnet, oracle, dev):
     x4 = np.zeros((3, 224, 224, 4), dtype=np.float32)
     x4[..., :3] = x.transpose(0, 2, 3, 1)
     got4 = resnet.get_vec(torch.from_numpy(x4).to(dev), channels_last4=True).cpu().numpy()
-    np.testing.assert_array_equal(got4, got)
+    assert np.abs(got4 - got).max() / scale < 1e-5      # the stem sums its taps in another order on this layout (K = 196 vs 168)
+    assert np.abs(got4 - want).max() / scale < POOL5_RTOL * 10
 
 
 def test_resnet50_against_independent_third_party_implementation(resnet, golden, dev):
@@ -424,7 +425,8 @@ def test_head_mlp_hidden_units_variants(oracle, dev, units):
 
 def test_resnet50_input_layouts_agree(resnet, oracle, dev):
     """The three input layouts of mm_resnet50_forward -- NCHW (the reference's), NHWC4, zero-bordered packed NHWC3 (stem with K = 168
-    instead of 196: a different summation order in the first layer only) -- give the same pool5 features."""
+    instead of 196; NCHW input is converted to it, NHWC4 keeps the K = 196 form: a different summation order in the first layer only)
+    -- give the same pool5 features."""
     x = _images(3, 11)
     want = oracle.resnet50_pool5(weights.make_resnet50_state_dict(seed=0), x)
     xt = torch.from_numpy(x).to(dev)
@@ -435,9 +437,9 @@ def test_resnet50_input_layouts_agree(resnet, oracle, dev):
     x3 = torch.zeros(3, 230, 230, 3, device=dev)
     x3[:, 3:227, 3:227, :] = xt.permute(0, 2, 3, 1)
     c = resnet.get_vec(x3)
-    assert torch.equal(a, b)
+    assert torch.equal(a, c)                    # NCHW is converted to the packed layout: same kernels
     scale = np.abs(want).max()
-    for got in (a, c):
+    for got in (a, b):
         g = got.cpu().numpy()
         assert np.abs(g - want).max() / scale < POOL5_RTOL * 10 and np.abs(g - want).mean() / scale < POOL5_RTOL
-    assert (a - c).abs().max().item() / scale < 1e-5
+    assert (a - b).abs().max().item() / scale < 1e-5

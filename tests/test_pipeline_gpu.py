@@ -72,11 +72,11 @@ def test_tester_reads_reference_directory_layout(tester, oracle, tmp_path):
     want = _oracle_video(oracle, clip)
     assert np.abs(res["utt"].values - want).max() < OUT_ATOL
     # test() decodes on the host and preprocesses on the GPU; the host-side PIL preprocessing (used for frame sizes
-    # other than save_size) feeds the same pixel values (the GPU kernels are bit-exact with PIL) through the NCHW entry point,
-    # whose stem sums its 7x7x3 taps in another order than the packed-row stem of the uint8 path: fp32 rounding only
+    # other than save_size) gives the same bits, because the GPU kernels are bit-exact with PIL and the NCHW entry point
+    # converts to the same packed-row layout the uint8 path writes
     paths = [p for _, p in sampler.list_aligned_frames(str(tmp_path / "utt_opface"), "utt")]
     host = tester._run([12], sampler.load_gray_batch(paths, 48).to(tester.device), sampler.load_rgb_batch(paths).to(tester.device))
-    assert np.abs(host[0] - res["utt"].values).max() < 5e-6
+    np.testing.assert_array_equal(host[0], res["utt"].values)
     # Resnet50_Extractor.run writes one %05d.npy per frame and skips when they exist (api/resnet50_extractor.py:61-72)
     out_dir = tmp_path / "utt_pool5"
     tester.resnet50_extractor.run(str(tmp_path / "utt_opface"), str(out_dir), video_name="utt")
