@@ -84,25 +84,64 @@ wino_fused_kernel(const WinoFusedParams p) {
         asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds\n\ts_mov_b32 m0, %0"
                      : "=&s"(keep) : "v"(voff), "s"(rsrc), "s"(m0v) : "memory");
     };
+    // The DMA stream runs NBUF-1 slabs ahead of the MFMAs, through the slab sequence (column q outer, row r, k slab inner; position
+    // plane xi = r * 6 + q).  Its state advances incrementally -- plane pointers by +6 planes per position and -29 at a column
+    // change, the k offset by 256 bytes -- because with two waves per SIMD the scalar bookkeeping of a slab is paid in issue slots
+    // (rocprofv3: 2.6 SALU instructions per MFMA with per-slab 64-bit multiplies; the MFMAs of a slab take 1 024 cycles).
+    const char* pv = reinterpret_cast<const char*>(p.V);
+    const char* pu = reinterpret_cast<const char*>(p.U);
+    const int64_t step_a = 6 * (int64_t)plane_a, step_b = 6 * (int64_t)plane_b;
+    const int64_t back_a = 35 * (int64_t)plane_a, back_b = 35 * (int64_t)plane_b;
+    unsigned rec_a = plane_a, rec_b = plane_b;     // num_records: 0 past the last slab (loads return zeros into a dead slot)
+    unsigned koff = 0;
     int d_q = 0, d_r = 0, d_ks = 0, d_buf = 0;
     auto dma_next = [&]() {
-        const bool live = d_q < 6;
-        const int xi = live ? d_r * 6 + d_q : 0;
-        const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(
-            const_cast<float*>(p.V) + (int64_t)xi * p.ntile * K, 0, live ? plane_a : 0u, 0x00020000);
-        const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(
-            const_cast<float*>(p.U) + (int64_t)xi * p.Cout * K, 0, live ? plane_b : 0u, 0x00020000);
-        const unsigned koff = (unsigned)d_ks * (KS * 4u);
-        const unsigned base = lds0 + (unsigned)d_buf * SLAB_BYTES + (unsigned)wave * 1024u;
-#pragma unroll
-        for (int it = 0; it < NIA; ++it) dma1(ra, va[it] + koff, base + it * (NW * 1024));
-#pragma unroll
-        for (int it = 0; it < NIB; ++it) dma1(rb, vb[it] + koff, base + BM * (KS * 4) + it * (NW * 1024));
-        const bool wrap_k = d_ks + 1 == kslabs;
-        d_ks = wrap_k ? 0 : d_ks + 1;
-        const bool wrap_r = wrap_k && d_r == 5;
-        d_r = wrap_k ? (wrap_r ? 0 : d_r + 1) : d_r;
-        d_q += wrap_r ? 1 : 0;
+        const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(pv), 0, rec_a, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(pu), 0, rec_b, 0x00020000);
+        const unsigned base = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)d_buf * SLAB_BYTES + (unsigned)wave * 1024u);
+        // all pieces of the slab in ONE statement: M0 (compiler-reserved) is saved and restored once, and each piece is
+        // s_add_u32 m0 / s_nop / buffer_load (three instructions instead of six)
+        unsigned keep;
+        if constexpr (NIA == 2 && NIB == 4) {
+            asm volatile("s_mov_b32 %0, m0\n\t"
+                         "s_add_u32 m0, %9, %10\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %7, 0 offen lds\n\t"
+                         "s_add_u32 m0, %9, %11\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %7, 0 offen lds\n\t"
+                         "s_add_u32 m0, %9, %12\n\ts_nop 0\n\tbuffer_load_dwordx4 %3, %8, 0 offen lds\n\t"
+                         "s_add_u32 m0, %9, %13\n\ts_nop 0\n\tbuffer_load_dwordx4 %4, %8, 0 offen lds\n\t"
+                         "s_add_u32 m0, %9, %14\n\ts_nop 0\n\tbuffer_load_dwordx4 %5, %8, 0 offen lds\n\t"
+                         "s_add_u32 m0, %9, %15\n\ts_nop 0\n\tbuffer_load_dwordx4 %6, %8, 0 offen lds\n\t"
+                         "s_mov_b32 m0, %0"
+                         : "=&s"(keep)
+                         : "v"(va[0] + koff), "v"(va[1] + koff), "v"(vb[0] + koff), "v"(vb[1] + koff), "v"(vb[2] + koff), "v"(vb[3] + koff),
+                           "s"(ra), "s"(rb), "s"(base), "n"(0), "n"(NW * 1024), "n"(BM * KS * 4), "n"(BM * KS * 4 + NW * 1024),
+                           "n"(BM * KS * 4 + 2 * NW * 1024), "n"(BM * KS * 4 + 3 * NW * 1024)
+                         : "memory", "scc");
+        } else {
+            static_assert(NIA == 2 && NIB == 2, "piece counts of the two workgroup shapes");
+            asm volatile("s_mov_b32 %0, m0\n\t"
+                         "s_add_u32 m0, %7, %8\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %5, 0 offen lds\n\t"
+                         "s_add_u32 m0, %7, %9\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %5, 0 offen lds\n\t"
+                         "s_add_u32 m0, %7, %10\n\ts_nop 0\n\tbuffer_load_dwordx4 %3, %6, 0 offen lds\n\t"
+                         "s_add_u32 m0, %7, %11\n\ts_nop 0\n\tbuffer_load_dwordx4 %4, %6, 0 offen lds\n\t"
+                         "s_mov_b32 m0, %0"
+                         : "=&s"(keep)
+                         : "v"(va[0] + koff), "v"(va[1] + koff), "v"(vb[0] + koff), "v"(vb[1] + koff), "s"(ra), "s"(rb), "s"(base), "n"(0),
+                           "n"(NW * 1024), "n"(BM * KS * 4), "n"(BM * KS * 4 + NW * 1024)
+                         : "memory", "scc");
+        }
+        koff += KS * 4u;
+        if (++d_ks == kslabs) {            // next position
+            d_ks = 0;
+            koff = 0;
+            pv += step_a;
+            pu += step_b;
+            if (++d_r == 6) {              // next column
+                d_r = 0;
+                pv -= back_a;
+                pu -= back_b;
+                if (++d_q == 6) rec_a = rec_b = 0;
+            }
+        }
         d_buf = d_buf == NBUF - 1 ? 0 : d_buf + 1;
     };
 
