@@ -1,3 +1,4 @@
+// Build: hipcc --offload-arch=gfx950 -O2 tools/probes/unaligned_dma.hip -o tools/probes/unaligned_dma ; run it on the GPU box.
 // Does `buffer_load_dwordx4 ... lds` accept a global address that is only 4-byte aligned (gfx950)?  Each lane loads 16 bytes from
 // base + lane * 16 + shift (shift = 0, 4, 8, 12) into LDS and the kernel copies LDS back out; the host checks the values.
 #include <hip/hip_runtime.h>
