@@ -257,7 +257,7 @@ def parse_args(argv=None):
     ap.add_argument("--distinct-clips", type=int, default=0,
                     help="distinct synthetic clip contents (clip id mod this); default min(total, 2 x clips)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-extra", action="store_true", help="skip the direct-form / fp32-input / multi-snippet legs")
+    ap.add_argument("--no-extra", action="store_true", help="skip the direct-form / multi-snippet legs (extra)")
     ap.add_argument("--extra-steps", type=int, default=5)
     ap.add_argument("--backend", default=None, help="torch.distributed backend for N>1 (default nccl = RCCL on a GPU host; "
                     "gloo only for plumbing tests, e.g. two ranks on one GPU with --same-device)")
