@@ -25,6 +25,11 @@ struct ConvParams {
     int batch;       // >1: `batch` independent problems of this shape in one launch (0/1 = single)
     int64_t in_bstride, w_bstride, out_bstride;   // element strides between the problems of a batch
     int M, tiles_m, tiles_n;  // filled by conv_forward
+    // second K source of a 1x1 layer (null = none): out = W[:, :Cin] * in(pixel) + W[:, Cin:] * in2(pixel * stride2), i.e. a residual
+    // block's increase conv and its projection shortcut as ONE contraction over K = Cin + C2 (the shortcut tensor is never written
+    // or re-read).  in2 is NHWC [B, H2, W2, in2_cstride]; needs kh = kw = 1, pad = 0, stride = 1, Cin % 16 == 0, C2 % 16 == 0.
+    const float* in2;
+    int H2, W2, C2, in2_cstride, in2_coff, stride2;
 };
 
 int conv_forward(const ConvParams& p, hipStream_t stream);

@@ -49,6 +49,8 @@ constexpr int CLD = 16;   // LDS row = one 16-float chunk; the four 16-byte slot
 //      floats of a kernel row padded to RG = a multiple of 4 (7 x 3 = 21 -> 24: K = 168 instead of 7 * 7 * 4 = 196 -> 208); a
 //      k-quad is 4 consecutive floats of the input row -- 4-byte aligned only, which the LDS-DMA accepts (tools/probes/unaligned_dma.hip)
 //      -- and the three floats past a row group meet zero weights.  No border logic: pad must be 0.
+//   6  1x1 kernel over TWO inputs (ConvParams::in2): chunks [0, Cin/16) come from `in`, the rest from `in2` sampled at stride2 --
+//      increase conv + projection shortcut of a residual block in one accumulation (the chunk -> source choice is wave-uniform)
 template <int BM, int BN, int WGM, int WGN, int KMODE, bool ABL = false>
 __global__ void __launch_bounds__(WGM * WGN * 64)
 conv_mfma_kernel(const ConvParams p) {
@@ -107,11 +109,16 @@ conv_mfma_kernel(const ConvParams p) {
     const __amdgpu_buffer_rsrc_t rsrc_b =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(w_b), 0, (unsigned)((int64_t)p.Cout * p.Kpad * 4), 0x00020000);
     constexpr unsigned OOB = 0xFFFFFFFFu;
+    const int64_t img_elems2 = KMODE == 6 ? (int64_t)p.H2 * p.W2 * p.in2_cstride : 0;
+    const int64_t rem_elems2 = ((int64_t)p.B - img0) * img_elems2;
+    const unsigned a2_bytes = rem_elems2 * 4 > 0xFFFFF000ll ? 0xFFFFF000u : (unsigned)(rem_elems2 * 4);
+    const __amdgpu_buffer_rsrc_t rsrc_a2 = KMODE == 6
+        ? __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.in2) + img0 * img_elems2, 0, a2_bytes, 0x00020000) : rsrc_a;
 
     // DMA lane mapping: wave w, instruction `it` covers rows (it*4 + w)*16 .. +15; lane l -> row + (l >> 2), slot l & 3
     const int lrow = wave * 16 + (lane >> 2);            // + RPR * it
     const int kq = (lane & 3) ^ ((lrow >> 2) & 3);       // k-quad stored in this lane's slot (same for every it)
-    int a_hi0[AIT], a_wi0[AIT], a_pix[AIT];
+    int a_hi0[AIT], a_wi0[AIT], a_pix[AIT], a_pix2[AIT];
     bool a_ok[AIT];
 #pragma unroll
     for (int it = 0; it < AIT; ++it) {
@@ -124,6 +131,8 @@ conv_mfma_kernel(const ConvParams p) {
         a_wi0[it] = wo * p.stride - p.pad;
         // element offset of tap (0,0), channel 0, relative to the descriptor base (may be negative: padding)
         a_pix[it] = (b - img0) * (int)img_elems + (a_hi0[it] * p.W + a_wi0[it]) * p.in_cstride + p.in_coff;
+        a_pix2[it] = KMODE == 6 ? (b - img0) * (int)img_elems2 + (ho * p.stride2 * p.W2 + wo * p.stride2) * p.in2_cstride + p.in2_coff - p.Cin
+                                : 0;   // - Cin: the second source is indexed with the running k
     }
     unsigned vb[BIT];
 #pragma unroll
@@ -165,6 +174,12 @@ conv_mfma_kernel(const ConvParams p) {
         if (KMODE == 3) {
 #pragma unroll
             for (int it = 0; it < AIT; ++it) va[it] = (kok && a_ok[it]) ? (unsigned)(a_pix[it] + tk) * 4u : OOB;
+            return;
+        }
+        if (KMODE == 6) {
+            const bool second = tk >= p.Cin;
+#pragma unroll
+            for (int it = 0; it < AIT; ++it) va[it] = (kok && a_ok[it]) ? (unsigned)((second ? a_pix2[it] : a_pix[it]) + tk) * 4u : OOB;
             return;
         }
         const int tapoff = (tr * p.W + ts) * p.in_cstride + tc;
@@ -219,9 +234,17 @@ conv_mfma_kernel(const ConvParams p) {
         asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds\n\ts_mov_b32 m0, %0"
                      : "=&s"(keep) : "v"(voff), "s"(rsrc), "s"(m0v) : "memory");
     };
+    int dchunk = 0;                       // chunk the next dma() fetches (KMODE 6: which source)
+    const int nk1 = p.Cin / CBK;
     auto dma = [&](int buf) {
+        if (KMODE == 6 && dchunk >= nk1) {
 #pragma unroll
-        for (int it = 0; it < AIT; ++it) dma1(rsrc_a, va[it], lds_a + ((buf * BM + (it * NW + wave) * 16) * CLD) * 4);
+            for (int it = 0; it < AIT; ++it) dma1(rsrc_a2, va[it], lds_a + ((buf * BM + (it * NW + wave) * 16) * CLD) * 4);
+        } else {
+#pragma unroll
+            for (int it = 0; it < AIT; ++it) dma1(rsrc_a, va[it], lds_a + ((buf * BM + (it * NW + wave) * 16) * CLD) * 4);
+        }
+        ++dchunk;
 #pragma unroll
         for (int it = 0; it < BIT; ++it) dma1(rsrc_b, vb[it], lds_b + ((buf * BN + (it * NW + wave) * 16) * CLD) * 4);
     };
@@ -423,6 +446,7 @@ static int launch_km(ConvParams p, hipStream_t stream) {
 template <int BM, int BN, int WGM, int WGN>
 static int launch_cfg(const ConvParams& p, hipStream_t stream) {
     if (p.korder == 2) return launch_km<BM, BN, WGM, WGN, 5>(p, stream);
+    if (p.in2) return launch_km<BM, BN, WGM, WGN, 6>(p, stream);
     if (p.kh == 1 && p.kw == 1 && p.pad == 0) return launch_km<BM, BN, WGM, WGN, 3>(p, stream);
     if (p.korder == 1) return launch_km<BM, BN, WGM, WGN, 1>(p, stream);
     if (p.Cin >= CBK) return launch_km<BM, BN, WGM, WGN, 2>(p, stream);
@@ -447,6 +471,15 @@ int conv_forward(const ConvParams& p0, hipStream_t stream) {
         const int64_t hw_o = (int64_t)p.Ho * p.Wo;
         const int64_t span = 256 / (hw_o > 0 ? hw_o : 1) + 2;
         if (span * p.H * p.W * p.in_cstride * 4 >= 0x7FFFF000ll) return MM_ERR_INVALID_ARG;
+    }
+    if (p.in2) {
+        if (p.kh != 1 || p.kw != 1 || p.pad != 0 || p.stride != 1 || p.korder != 0 || p.batch > 1 || p.Cin % CBK || p.C2 <= 0 ||
+            p.C2 % CBK || p.K != p.Cin + p.C2 || p.Kpad != p.K || p.in2_cstride % 4 || p.in2_coff % 4 || p.stride2 <= 0 ||
+            (p.Ho - 1) * p.stride2 >= p.H2 || (p.Wo - 1) * p.stride2 >= p.W2)
+            return MM_ERR_INVALID_ARG;
+        const int64_t hw_o = (int64_t)p.Ho * p.Wo;
+        const int64_t span = 256 / (hw_o > 0 ? hw_o : 1) + 2;
+        if (span * p.H2 * p.W2 * p.in2_cstride * 4 >= 0x7FFFF000ll) return MM_ERR_INVALID_ARG;
     }
     p.M = p.B * p.Ho * p.Wo;
     if (p.M <= 0) return MM_OK;
@@ -482,6 +515,7 @@ int conv_forward(const ConvParams& p0, hipStream_t stream) {
         case 4: return launch_cfg<256, 64, 4, 1>(p, stream);
         case 5:   // 128x256, eight waves: the whole N of a 256-channel 1x1 layer in one workgroup (A read once)
             if (!(p.kh == 1 && p.kw == 1 && p.pad == 0)) return MM_ERR_INVALID_ARG;
+            if (p.in2) return launch_km<128, 256, 2, 4, 6>(p, stream);
             return launch_km<128, 256, 2, 4, 3>(p, stream);
         default: return MM_ERR_INVALID_ARG;
     }

@@ -152,6 +152,26 @@ static int make_layer(DeviceArena& A, Layer& L, const float* w, const float* bia
     return rc;
 }
 
+// A residual block's increase conv (w1 [cout][c1], BN bn1) and its projection shortcut (w2 [cout][c2], BN bn2) as one 1x1 layer over
+// K = c1 + c2: relu(BN1(w1 a) + BN2(w2 x)) = relu([s1 w1 | s2 w2] [a; x] + (t1 + t2))  (conv_mfma.hip KMODE 6).
+static int make_layer_dual(DeviceArena& A, Layer& L, const float* w1, const BN& bn1, int c1, const float* w2, const BN& bn2, int c2,
+                           int cout, float eps) {
+    if (c1 % 16 || c2 % 16) return MM_ERR_UNSUPPORTED;
+    L.cin = c1; L.cin_p = c1; L.cout = cout; L.k = 1; L.stride = 1; L.pad = 0; L.relu = 1; L.korder = 0;
+    L.K = L.Kpad = c1 + c2;
+    std::vector<float> hw((size_t)cout * L.K), hb(cout);
+    for (int o = 0; o < cout; ++o) {
+        const double s1 = (double)bn1.gamma[o] / std::sqrt((double)bn1.var[o] + (double)eps);
+        const double s2 = (double)bn2.gamma[o] / std::sqrt((double)bn2.var[o] + (double)eps);
+        for (int c = 0; c < c1; ++c) hw[(size_t)o * L.K + c] = (float)((double)w1[(size_t)o * c1 + c] * s1);
+        for (int c = 0; c < c2; ++c) hw[(size_t)o * L.K + c1 + c] = (float)((double)w2[(size_t)o * c2 + c] * s2);
+        hb[o] = (float)(((double)bn1.beta[o] - (double)bn1.mean[o] * s1) + ((double)bn2.beta[o] - (double)bn2.mean[o] * s2));
+    }
+    int rc = A.upload(hw, &L.w);
+    if (rc == MM_OK) rc = A.upload(hb, &L.bias);
+    return rc;
+}
+
 static int run_layer(const Layer& L, const float* in, int B, int H, int W, int in_cstride, int in_coff, float* out,
                      int out_cstride, int out_coff, const float* res, int res_cstride, hipStream_t s, int* Ho_ = nullptr,
                      int* Wo_ = nullptr) {
@@ -172,6 +192,19 @@ static int run_layer(const Layer& L, const float* in, int B, int H, int W, int i
 
 // Stride-1 3x3 layer through Winograd F(2x2,3x3): input transform, ONE batched GEMM launch (16 problems), output
 // transform with the fused bias/ReLU.  V and M are caller-provided scratch of 16*B*ceil(H/2)*ceil(W/2)*C floats.
+// out = relu(L over [in | in2 sampled at stride2]); in [B,H,W,L.cin], in2 [B,H2,W2,C2]
+static int run_layer_dual(const Layer& L, const float* in, int B, int H, int W, const float* in2, int H2, int W2, int C2, int stride2,
+                          float* out, hipStream_t s) {
+    ConvParams p;
+    std::memset(&p, 0, sizeof(p));
+    p.in = in; p.w = L.w; p.bias = L.bias; p.out = out;
+    p.B = B; p.H = H; p.W = W; p.Cin = L.cin; p.in_cstride = L.cin; p.Ho = H; p.Wo = W;
+    p.Cout = L.cout; p.out_cstride = L.cout; p.kh = 1; p.kw = 1; p.stride = 1;
+    p.K = L.K; p.Kpad = L.Kpad; p.relu = 1; p.Cin_real = L.K;
+    p.in2 = in2; p.H2 = H2; p.W2 = W2; p.C2 = C2; p.in2_cstride = C2; p.stride2 = stride2;
+    return conv_forward(p, s);
+}
+
 static int g_wino_fused_max_cin = 256;   // measurement knob (MM_WF_MAX_CIN)
 static int g_wino_fused_shape = 0;   // measurement knob (MM_WINO_FUSED_SHAPE): workgroup shape of the fused kernel, 0 = auto
 
@@ -217,6 +250,8 @@ static const int kStages[4][4] = {{3, 64, 256, 1}, {4, 128, 512, 2}, {6, 256, 10
 
 struct Bottleneck {
     Layer proj, reduce, conv3, increase;
+    Layer inc_proj;   // increase + projection shortcut as one contraction (make_layer_dual); w == null when not built
+    int proj_stride;
     bool has_proj;
 };
 
@@ -229,6 +264,7 @@ struct mm_resnet50 {
     std::vector<mm::Bottleneck> blocks;
     int ceil_mode;
     int winograd;  // 0 direct, 2 = F(2x2,3x3), 4 = F(4x4,3x3) for the layers that have Winograd-domain weights
+    int fuse_proj; // 1 (default): the first block of a stage runs increase + projection as one launch
     int device;
 };
 
@@ -329,6 +365,10 @@ int mm_resnet50_create(mm_resnet50_t** out, const float* blob, int64_t n_floats,
     const float* p = blob;
     int rc = MM_OK;
     h->winograd = 1;
+    {
+        const char* fp = getenv("MM_FUSE_PROJ");   // measurement knob: 0 = projection shortcut as its own launch + residual read
+        h->fuse_proj = fp ? atoi(fp) : 1;
+    }
     auto conv_bn = [&](Layer& L, int cout, int cin, int k, int stride, int pad, int relu) {
         const float* w = p;
         p += (int64_t)cout * cin * k * k;
@@ -350,10 +390,20 @@ int mm_resnet50_create(mm_resnet50_t** out, const float* blob, int64_t n_floats,
             h->blocks.emplace_back();
             Bottleneck& B = h->blocks.back();
             B.has_proj = b == 0;
+            B.proj_stride = s;
+            const float* w_proj = p;
             if (b == 0) conv_bn(B.proj, cout, cin, 1, s, 0, 0);
             conv_bn(B.reduce, mid, cin, 1, s1, 0, 1);
             conv_bn(B.conv3, mid, mid, 3, s3, 1, 1);
+            const float* w_inc = p;
             conv_bn(B.increase, cout, mid, 1, 1, 0, 1);  // ReLU applies after the residual add (fused epilogue)
+            if (b == 0 && rc == MM_OK) {
+                const float* q1 = w_inc + (int64_t)cout * mid;
+                const float* q2 = w_proj + (int64_t)cout * cin;
+                const BN bn1{q1, q1 + cout, q1 + 2 * cout, q1 + 3 * cout}, bn2{q2, q2 + cout, q2 + 2 * cout, q2 + 3 * cout};
+                const int rd = make_layer_dual(h->arena, B.inc_proj, w_inc, bn1, mid, w_proj, bn2, cin, cout, bn_eps);
+                if (rd != MM_OK && rd != MM_ERR_UNSUPPORTED) rc = rd;
+            }
             cin = cout;
         }
     if (rc != MM_OK) {
@@ -444,7 +494,8 @@ int mm_resnet50_forward(mm_resnet50_t* h, const float* images, int nchw, int64_t
         float* o = big[(xi + 2) % 3];
         int H1, W1, H2, W2, H3, W3;
         const float* resid = x;
-        if (Bk.has_proj) {
+        const bool dual = Bk.has_proj && h->fuse_proj && Bk.inc_proj.w;
+        if (Bk.has_proj && !dual) {
             rc = run_layer(Bk.proj, x, B, H, W, C, 0, sc, Bk.proj.cout, 0, nullptr, 0, s);
             if (rc != MM_OK) return rc;
             resid = sc;
@@ -463,7 +514,13 @@ int mm_resnet50_forward(mm_resnet50_t* h, const float* images, int nchw, int64_t
             rc = run_layer(Bk.conv3, y1, B, H1, W1, Bk.reduce.cout, 0, y2, Bk.conv3.cout, 0, nullptr, 0, s, &H2, &W2);
         }
         if (rc != MM_OK) return rc;
-        rc = run_layer(Bk.increase, y2, B, H2, W2, Bk.conv3.cout, 0, o, Bk.increase.cout, 0, resid, Bk.increase.cout, s, &H3, &W3);
+        if (dual) {
+            // relu(BN(increase(y2)) + BN(proj(x))) in one accumulation: the shortcut tensor is never written or re-read
+            rc = run_layer_dual(Bk.inc_proj, y2, B, H2, W2, x, H, W, C, Bk.proj_stride, o, s);
+            H3 = H2; W3 = W2;
+        } else {
+            rc = run_layer(Bk.increase, y2, B, H2, W2, Bk.conv3.cout, 0, o, Bk.increase.cout, 0, resid, Bk.increase.cout, s, &H3, &W3);
+        }
         if (rc != MM_OK) return rc;
         H = H3; W = W3; C = Bk.increase.cout;
         xi = (xi + 2) % 3;

@@ -443,3 +443,28 @@ def test_resnet50_input_layouts_agree(resnet, oracle, dev):
         g = got.cpu().numpy()
         assert np.abs(g - want).max() / scale < POOL5_RTOL * 10 and np.abs(g - want).mean() / scale < POOL5_RTOL
     assert (a - b).abs().max().item() / scale < 1e-5
+
+
+def test_resnet50_fused_projection_blocks(resnet, oracle, dev, monkeypatch):
+    """First block of every stage: increase conv + projection shortcut as ONE contraction over K = mid + Cin (conv_mfma.hip KMODE 6;
+    strides 1 and 2 on the shortcut's source) against the two-launch form (MM_FUSE_PROJ=0: shortcut written, re-read as the residual)
+    and the oracle.  Same products, one summation order instead of two rounded sums: not bit-equal, far inside the tolerance."""
+    from mimamo_net_amd.resnet50_extractor import Resnet50_Extractor
+    monkeypatch.setenv("MM_FUSE_PROJ", "0")
+    split = Resnet50_Extractor(state_dict=weights.make_resnet50_state_dict(seed=0), device=dev)
+    monkeypatch.delenv("MM_FUSE_PROJ")
+    x = _images(3, 13)
+    want = oracle.resnet50_pool5(weights.make_resnet50_state_dict(seed=0), x)
+    xt = torch.from_numpy(x).to(dev)
+    scale = np.abs(want).max()
+    try:
+        for mode in (1, 0):
+            resnet.set_winograd(mode)
+            split.set_winograd(mode)
+            a, b = resnet.get_vec(xt).cpu().numpy(), split.get_vec(xt).cpu().numpy()
+            assert not np.array_equal(a, b)                      # the knob really switches the schedule
+            assert np.abs(a - b).max() / scale < 1e-5, np.abs(a - b).max() / scale
+            for g in (a, b):
+                assert np.abs(g - want).max() / scale < POOL5_RTOL * 10 and np.abs(g - want).mean() / scale < POOL5_RTOL
+    finally:
+        resnet.set_winograd(True)
