@@ -45,7 +45,9 @@ int avgpool_hw(const float* in, float* out, int64_t N, int HW, int C, int out_cs
 // Winograd F(m x m, 3x3) transforms around a batched GEMM (winograd.hip), m = 2 or 4, a = m + 2
 //   input : x NHWC [B,H,W,C] (pad 1)             -> V [a*a][B*TH*TW][C],  TH = ceil(H/m), TW = ceil(W/m)
 //   output: M [a*a][B*TH*TW][Cout] + bias, ReLU  -> y NHWC [B,H,W,Cout]
-int wino_input_transform(const float* x, float* V, int B, int H, int W, int C, int m, hipStream_t s);
+//   x_channels (m = 4 only; 0 = C): x has x_channels <= C channels per pixel, channels [x_channels, C) of V are zero (K padded to the
+//   GEMM kernels' granularity; the matching weight columns are zero too)
+int wino_input_transform(const float* x, float* V, int B, int H, int W, int C, int m, hipStream_t s, int x_channels = 0);
 int wino_output_transform(const float* M, const float* bias, float* y, int B, int H, int W, int Cout, int relu, int m, hipStream_t s);
 
 // F(4x4,3x3) position GEMMs + output transform in one kernel (wino_fused.hip): V [36][tiles][Cin] (wino_input_transform, m = 4),

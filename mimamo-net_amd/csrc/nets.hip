@@ -21,6 +21,7 @@ struct Layer {
     float* wino_u = nullptr;   // [16][cout][cin] F(2x2,3x3)-domain weights (stride-1 3x3 layers with cin >= 128), or null
     float* wino_u4 = nullptr;  // [36][cout][cin] F(4x4,3x3)-domain weights
     int cin = 0, cin_p = 0, cout = 0, k = 1, stride = 1, pad = 0, K = 0, Kpad = 0, relu = 0, korder = 0;
+    int wino_cin = 0;          // channels of the Winograd-domain weights: cin, or cin padded with zero columns (wino_pad)
 };
 
 struct DeviceArena {
@@ -48,7 +49,8 @@ struct BN {
 // Build one conv/linear layer from host tensors.  w: [cout][cin][k][k] (OIHW), bias may be null.
 // fold: BN directly after the conv (scale into the weights).  post: BN after the ReLU.
 static int make_layer(DeviceArena& A, Layer& L, const float* w, const float* bias, int cout, int cin, int k, int stride,
-                      int pad, int relu, const BN* fold, const BN* post, float eps, bool wino = false, bool packed3 = false) {
+                      int pad, int relu, const BN* fold, const BN* post, float eps, bool wino = false, bool packed3 = false,
+                      int wino_pad = 0) {
     if (packed3) {
         // 3-channel input rows packed NHWC3 with the zero border in memory (conv_mfma.hip KMODE 5): k = r * RG + s * 3 + c, RG = the
         // k * 3 floats of a kernel row rounded up to a multiple of 4 (zero weights in the slack)
@@ -102,10 +104,13 @@ static int make_layer(DeviceArena& A, Layer& L, const float* w, const float* bia
     }
     int rc = A.upload(hw, &L.w);
     if (rc == MM_OK) rc = A.upload(hb, &L.bias);
-    if (rc == MM_OK && wino && k == 3 && stride == 1 && pad == 1 && cin % 16 == 0 && cin >= 64 && cout % 4 == 0) {
+    // wino_pad: Winograd-domain K rounded up to a multiple of it with zero columns (a 88-channel input on the 64-deep fused kernel)
+    const int wcin = wino_pad > 0 ? (cin + wino_pad - 1) / wino_pad * wino_pad : cin;
+    if (rc == MM_OK && wino && k == 3 && stride == 1 && pad == 1 && wcin % 16 == 0 && cin >= 64 && cin % 4 == 0 && cout % 4 == 0) {
+        L.wino_cin = wcin;
         // U = G g G^T, G = [1 0 0; .5 .5 .5; .5 -.5 .5; 0 0 1], on the BN-folded filter, float64 -> fp32
         static const double G[4][3] = {{1, 0, 0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0, 0, 1}};
-        std::vector<float> hu((size_t)16 * cout * cin);
+        std::vector<float> hu((size_t)16 * cout * wcin, 0.f);
         for (int o = 0; o < cout; ++o) {
             const double sc = fold ? (double)fold->gamma[o] / std::sqrt((double)fold->var[o] + (double)eps) : 1.0;
             for (int c = 0; c < cin; ++c) {
@@ -116,14 +121,14 @@ static int make_layer(DeviceArena& A, Layer& L, const float* w, const float* bia
                     for (int q = 0; q < 3; ++q) t[i][q] = G[i][0] * g[0][q] + G[i][1] * g[1][q] + G[i][2] * g[2][q];
                 for (int i = 0; i < 4; ++i)
                     for (int j = 0; j < 4; ++j)
-                        hu[((size_t)(i * 4 + j) * cout + o) * cin + c] = (float)(t[i][0] * G[j][0] + t[i][1] * G[j][1] + t[i][2] * G[j][2]);
+                        hu[((size_t)(i * 4 + j) * cout + o) * wcin + c] = (float)(t[i][0] * G[j][0] + t[i][1] * G[j][1] + t[i][2] * G[j][2]);
             }
         }
         rc = A.upload(hu, &L.wino_u);
         // F(4x4,3x3): G = [1/4 0 0; -1/6 -1/6 -1/6; -1/6 1/6 -1/6; 1/24 1/12 1/6; 1/24 -1/12 1/6; 0 0 1]
         static const double G4[6][3] = {{0.25, 0, 0}, {-1.0 / 6, -1.0 / 6, -1.0 / 6}, {-1.0 / 6, 1.0 / 6, -1.0 / 6},
                                         {1.0 / 24, 1.0 / 12, 1.0 / 6}, {1.0 / 24, -1.0 / 12, 1.0 / 6}, {0, 0, 1}};
-        std::vector<float> hu4((size_t)36 * cout * cin);
+        std::vector<float> hu4((size_t)36 * cout * wcin, 0.f);
         for (int o = 0; o < cout && rc == MM_OK; ++o) {
             const double sc = fold ? (double)fold->gamma[o] / std::sqrt((double)fold->var[o] + (double)eps) : 1.0;
             for (int c = 0; c < cin; ++c) {
@@ -134,7 +139,7 @@ static int make_layer(DeviceArena& A, Layer& L, const float* w, const float* bia
                     for (int q = 0; q < 3; ++q) t[i][q] = G4[i][0] * g[0][q] + G4[i][1] * g[1][q] + G4[i][2] * g[2][q];
                 for (int i = 0; i < 6; ++i)
                     for (int j = 0; j < 6; ++j)
-                        hu4[((size_t)(i * 6 + j) * cout + o) * cin + c] = (float)(t[i][0] * G4[j][0] + t[i][1] * G4[j][1] + t[i][2] * G4[j][2]);
+                        hu4[((size_t)(i * 6 + j) * cout + o) * wcin + c] = (float)(t[i][0] * G4[j][0] + t[i][1] * G4[j][1] + t[i][2] * G4[j][2]);
             }
         }
         if (rc == MM_OK) rc = A.upload(hu4, &L.wino_u4);
@@ -215,18 +220,21 @@ static int run_layer_wino(const Layer& L, const float* in, int B, int H, int W, 
     if (ntile > 0x7fffffff) return MM_ERR_INVALID_ARG;
     const bool fused = m == 5;          // F(4x4,3x3) with the output transform inside the GEMM kernel (wino_fused.hip)
     if (fused) m = 4;
-    int rc = wino_input_transform(in, V, B, H, W, L.cin, m, s);
+    const int wc = L.wino_cin;          // K of the position GEMMs (= cin unless the layer was built with zero-padded columns)
+    if (wc != L.cin_p && m != 4) return MM_ERR_UNSUPPORTED;
+    int rc = wino_input_transform(in, V, B, H, W, wc, m, s, L.cin_p);
     if (rc != MM_OK) return rc;
     if (fused) {
-        rc = wino_gemm_output_fused(V, L.wino_u4, L.bias, out, B, H, W, L.cin, L.cout, L.relu, g_wino_fused_shape, s);
+        rc = wino_gemm_output_fused(V, L.wino_u4, L.bias, out, B, H, W, wc, L.cout, L.relu, g_wino_fused_shape, s);
         if (rc != MM_ERR_UNSUPPORTED) return rc;
     }
+    if (!M) return MM_ERR_UNSUPPORTED;  // caller provided no plane set for the three-kernel form
     ConvParams p;
     std::memset(&p, 0, sizeof(p));
     p.in = V; p.w = m == 4 ? L.wino_u4 : L.wino_u; p.out = M;
-    p.B = (int)ntile; p.H = 1; p.W = 1; p.Cin = L.cin; p.in_cstride = L.cin; p.Ho = 1; p.Wo = 1;
-    p.Cout = L.cout; p.out_cstride = L.cout; p.kh = 1; p.kw = 1; p.stride = 1; p.K = L.cin; p.Kpad = L.cin; p.Cin_real = L.cin;
-    p.batch = npos; p.in_bstride = ntile * L.cin; p.w_bstride = (int64_t)L.cout * L.cin; p.out_bstride = ntile * L.cout;
+    p.B = (int)ntile; p.H = 1; p.W = 1; p.Cin = wc; p.in_cstride = wc; p.Ho = 1; p.Wo = 1;
+    p.Cout = L.cout; p.out_cstride = L.cout; p.kh = 1; p.kw = 1; p.stride = 1; p.K = wc; p.Kpad = wc; p.Cin_real = wc;
+    p.batch = npos; p.in_bstride = ntile * wc; p.w_bstride = (int64_t)L.cout * wc; p.out_bstride = ntile * L.cout;
     rc = conv_forward(p, s);
     if (rc != MM_OK) return rc;
     return wino_output_transform(M, L.bias, out, B, H, W, L.cout, L.relu, m, s);
@@ -274,6 +282,7 @@ struct mm_head {
     int feat_dim, mlp_max;        // hidden_units[0] (width of the rgb features), widest hidden layer
     mm::Layer conv[6], fc1, fc2, transform, gru_ih[2], gru_hh[2][2], classifier;
     float* bhh[2][2];
+    int winograd;   // 1 (default): PhaseNet's 128 -> 256 3x3 layer through the fused F(4x4,3x3) kernel; MM_HEAD_WINOGRAD=0: direct form
     int device;
 };
 
@@ -565,13 +574,19 @@ int mm_head_create_mlp(mm_head_t** out, const float* blob, int64_t n_floats, int
     // Conv3x3(+bias) -> BN -> ReLU  (PhaseNet._make_conv_layer, :68-78)
     auto conv_bn_relu = [&](Layer& L, int o, int i, int stride) {
         const float* w = take((int64_t)o * i * 9); const float* b = take(o); BN bn = take_bn(o);
-        if (rc == MM_OK) rc = make_layer(h->arena, L, w, b, o, i, 3, stride, 1, 1, &bn, nullptr, eps);
+        // Winograd-domain weights for the fused F(4x4,3x3) kernel (stride 1, K a multiple of 64): 88 -> 128 at 24x24, 128 -> 256 at 12x12
+        // (the 88-channel concat layer gets 40 zero columns)
+        if (rc == MM_OK) rc = make_layer(h->arena, L, w, b, o, i, 3, stride, 1, 1, &bn, nullptr, eps, stride == 1 && i >= 64, false, 64);
     };
     // Linear -> ReLU -> BN  (PhaseNet.fc :54-62, transform :115-117)
     auto lin_relu_bn = [&](Layer& L, int o, int i) {
         const float* w = take((int64_t)o * i); const float* b = take(o); BN bn = take_bn(o);
         if (rc == MM_OK) rc = make_layer(h->arena, L, w, b, o, i, 1, 1, 0, 1, nullptr, &bn, eps);
     };
+    {
+        const char* e = getenv("MM_HEAD_WINOGRAD");   // measurement knob
+        h->winograd = e ? atoi(e) : 1;
+    }
     h->feat_dim = units[0];
     h->mlp_max = 256;
     h->mlp.resize(n_units - 1);
@@ -625,13 +640,14 @@ int mm_head_destroy(mm_head_t* h) {
 
 namespace {
 struct HeadWs {
-    int64_t p0n, a0, cat, a1, a2, a3, a4, pool, fc1, m1, feat, f, gi, gh, l0, l1;
+    int64_t p0n, a0, cat, a1, a2, a3, a4, pool, fc1, m1, feat, f, gi, gh, l0, l1, wv;
 };
 HeadWs head_sizes(int64_t N, int64_t T, int64_t mlp_max) {
     HeadWs s;
     s.p0n = N * 48 * 48 * 24; s.a0 = N * 48 * 48 * 64; s.cat = N * 24 * 24 * 88; s.a1 = N * 24 * 24 * 128;
     s.a2 = N * 12 * 12 * 128; s.a3 = N * 12 * 12 * 256; s.a4 = N * 6 * 6 * 256; s.pool = N * 256; s.fc1 = N * 256;
     s.m1 = 2 * N * mlp_max; s.feat = N * 512; s.f = N * 256; s.gi = N * 768; s.gh = T * 384; s.l0 = N * 256; s.l1 = N * 256;
+    s.wv = N * 36 * 36 * 128;   // Winograd planes of the 24x24 layer (36 positions x 36 tiles x 128 channels); the 12x12 layer's fit too
     return s;
 }
 }  // namespace
@@ -640,7 +656,7 @@ int64_t mm_head_workspace_bytes(mm_head_t* h, int64_t bs, int64_t T) {
     using mm::Bump;
     if (!h || bs < 0 || T < 0) return MM_ERR_INVALID_ARG;
     const HeadWs s = head_sizes(bs * T, T, h->mlp_max);
-    const int64_t all[] = {s.p0n, s.a0, s.cat, s.a1, s.a2, s.a3, s.a4, s.pool, s.fc1, s.m1, s.feat, s.f, s.gi, s.gh, s.l0, s.l1};
+    const int64_t all[] = {s.p0n, s.a0, s.cat, s.a1, s.a2, s.a3, s.a4, s.pool, s.fc1, s.m1, s.feat, s.f, s.gi, s.gh, s.l0, s.l1, s.wv};
     int64_t tot = 0;
     for (int64_t v : all) tot += Bump::size_of(v);
     return tot;
@@ -663,6 +679,7 @@ int mm_head_forward(mm_head_t* h, const float* phase_0, const float* phase_1, in
     float* a2 = ws.take(z.a2); float* a3 = ws.take(z.a3); float* a4 = ws.take(z.a4); float* pool = ws.take(z.pool);
     float* fc1 = ws.take(z.fc1); float* m1 = ws.take(z.m1); float* feat = ws.take(z.feat); float* f = ws.take(z.f);
     float* gi = ws.take(z.gi); float* gh = ws.take(z.gh); float* l0 = ws.take(z.l0); float* l1 = ws.take(z.l1);
+    float* wv = ws.take(z.wv);
     int rc;
 #define MM_TRY(x) do { rc = (x); if (rc != MM_OK) return rc; } while (0)
     // ---- temporal stream: PhaseNet (mimamo_net.py:79-92)
@@ -682,9 +699,17 @@ int mm_head_forward(mm_head_t* h, const float* phase_0, const float* phase_1, in
     }
     MM_TRY(run_layer(h->conv[0], x0, N, 48, 48, 24, 0, a0, 64, 0, nullptr, 0, s));
     MM_TRY(run_layer(h->conv[1], a0, N, 48, 48, 64, 0, cat, 88, 0, nullptr, 0, s));
-    MM_TRY(run_layer(h->conv[2], cat, N, 24, 24, 88, 0, a1, 128, 0, nullptr, 0, s));
+    if (h->winograd && h->conv[2].wino_u4) {
+        MM_TRY(run_layer_wino(h->conv[2], cat, N, 24, 24, a1, wv, nullptr, 5, s));   // K = 88 padded to 128 with zero columns
+    } else {
+        MM_TRY(run_layer(h->conv[2], cat, N, 24, 24, 88, 0, a1, 128, 0, nullptr, 0, s));
+    }
     MM_TRY(run_layer(h->conv[3], a1, N, 24, 24, 128, 0, a2, 128, 0, nullptr, 0, s));
-    MM_TRY(run_layer(h->conv[4], a2, N, 12, 12, 128, 0, a3, 256, 0, nullptr, 0, s));
+    if (h->winograd && h->conv[4].wino_u4) {
+        MM_TRY(run_layer_wino(h->conv[4], a2, N, 12, 12, a3, wv, nullptr, 5, s));   // 3x3 tiles per map
+    } else {
+        MM_TRY(run_layer(h->conv[4], a2, N, 12, 12, 128, 0, a3, 256, 0, nullptr, 0, s));
+    }
     MM_TRY(run_layer(h->conv[5], a3, N, 12, 12, 256, 0, a4, 256, 0, nullptr, 0, s));
     MM_TRY(avgpool_hw(a4, pool, N64, 36, 256, 256, 0, 0, s));
     MM_TRY(run_layer(h->fc1, pool, N, 1, 1, 256, 0, fc1, 256, 0, nullptr, 0, s));

@@ -150,7 +150,8 @@ __device__ __forceinline__ void at6(const float4 (&m)[6], float4 (&y)[4]) {
 }
 
 __global__ void __launch_bounds__(256)
-wino_in6_kernel(const float* __restrict__ x, float* __restrict__ V, int B, int H, int W, int C4, int TH, int TW, int64_t total) {
+wino_in6_kernel(const float* __restrict__ x, float* __restrict__ V, int B, int H, int W, int C4, int X4, int TH, int TW, int64_t total) {
+    // C4: channel quads of V; X4 <= C4: channel quads of x (its pixel stride): quads [X4, C4) of V are zero (K padded for the GEMMs)
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= total) return;
     const int c4 = (int)(i % C4);
@@ -167,8 +168,8 @@ wino_in6_kernel(const float* __restrict__ x, float* __restrict__ V, int B, int H
 #pragma unroll
         for (int q = 0; q < 6; ++q) {
             const int wx = 4 * tx - 1 + q;
-            const bool ok = (unsigned)hy < (unsigned)H && (unsigned)wx < (unsigned)W;
-            d[q] = ok ? src[((b * H + hy) * W + wx) * C4 + c4] : float4{0.f, 0.f, 0.f, 0.f};
+            const bool ok = (unsigned)hy < (unsigned)H && (unsigned)wx < (unsigned)W && c4 < X4;
+            d[q] = ok ? src[((b * H + hy) * W + wx) * X4 + c4] : float4{0.f, 0.f, 0.f, 0.f};
         }
         bt6(d, t[r]);
     }
@@ -226,14 +227,16 @@ wino_out6_kernel(const float* __restrict__ M, const float* __restrict__ bias, fl
     }
 }
 
-int wino_input_transform(const float* x, float* V, int B, int H, int W, int C, int m, hipStream_t s) {
-    if (C % 4 || (m != 2 && m != 4)) return MM_ERR_INVALID_ARG;
+int wino_input_transform(const float* x, float* V, int B, int H, int W, int C, int m, hipStream_t s, int x_channels) {
+    if (x_channels <= 0) x_channels = C;
+    if (C % 4 || (m != 2 && m != 4) || x_channels % 4 || x_channels > C || (m != 4 && x_channels != C)) return MM_ERR_INVALID_ARG;
     const int TH = (H + m - 1) / m, TW = (W + m - 1) / m;
     const int64_t total = (int64_t)B * TH * TW * (C / 4);
     if (total <= 0) return MM_OK;
     prof_before(3, (double)B * C * 4.0 * ((double)H * W + (double)((m + 2) * (m + 2)) * TH * TW), s);   // read x once, write the planes
     if (m == 4)
-        hipLaunchKernelGGL(wino_in6_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, x, V, B, H, W, C / 4, TH, TW, total);
+        hipLaunchKernelGGL(wino_in6_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, x, V, B, H, W, C / 4, x_channels / 4, TH,
+                           TW, total);
     else
         hipLaunchKernelGGL(wino_in_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, x, V, B, H, W, C / 4, TH, TW, total);
     prof_after(3, s);

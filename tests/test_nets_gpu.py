@@ -468,3 +468,27 @@ def test_resnet50_fused_projection_blocks(resnet, oracle, dev, monkeypatch):
                 assert np.abs(g - want).max() / scale < POOL5_RTOL * 10 and np.abs(g - want).mean() / scale < POOL5_RTOL
     finally:
         resnet.set_winograd(True)
+
+
+def test_phasenet_winograd_layers_vs_direct_form(head, oracle, dev, monkeypatch):
+    """PhaseNet's stride-1 3x3 layers with >= 64 input channels (88 -> 128 at 24x24 -- K padded to 128 with zero columns -- and
+    128 -> 256 at 12x12) run through the fused F(4x4,3x3) kernel; MM_HEAD_WINOGRAD=0 keeps them in the direct implicit-GEMM form.
+    Both against the oracle's direct convolutions, on ordinary inputs and on phase inputs at the clamp (|x| = 5 pi everywhere,
+    api/phase_difference_extractor.py:133: the largest magnitudes the network can be fed)."""
+    from mimamo_net_amd.mimamo_net import Two_Stream_RNN
+    sd = weights.make_two_stream_state_dict(seed=3)
+    p0, p1, rgb = _head_inputs(2, 16, 91)
+    monkeypatch.setenv("MM_HEAD_WINOGRAD", "0")
+    direct = Two_Stream_RNN().load_state_dict(sd).eval().to(dev)
+    direct(*[[torch.from_numpy(p0).to(dev), torch.from_numpy(p1).to(dev)], torch.from_numpy(rgb).to(dev)])   # the handle is built on first use
+    monkeypatch.delenv("MM_HEAD_WINOGRAD")
+    sign = np.sign(p0) + (p0 == 0), np.sign(p1) + (p1 == 0)
+    for name, (q0, q1) in {"ordinary": (p0, p1), "at the clamp": (5.0 * np.pi * sign[0], 5.0 * np.pi * sign[1])}.items():
+        q0, q1 = q0.astype(np.float32), q1.astype(np.float32)
+        want = oracle.two_stream_forward(sd, q0, q1, rgb)
+        t0, t1, tr = (torch.from_numpy(a).to(dev) for a in (q0, q1, rgb))
+        a, b = head([t0, t1], tr).cpu().numpy(), direct([t0, t1], tr).cpu().numpy()
+        ea, eb, ab = np.abs(a - want).max(), np.abs(b - want).max(), np.abs(a - b).max()
+        print("PhaseNet inputs %s: winograd %.2e direct %.2e apart %.2e" % (name, ea, eb, ab))
+        assert not np.array_equal(a, b)          # the knob really switches the kernels
+        assert ea < 2e-5 and eb < 2e-5 and ab < 2e-5, (name, ea, eb, ab)
