@@ -135,9 +135,16 @@ phase_frame_kernel(const float* __restrict__ polar, int64_t img_stride, int64_t 
     }
 }
 
-// ---- per (window, band): 12 phase-difference planes from the frame planes.  The 13 frames of a window are independent once the
-//      wrap counts are known (a running sum in registers), so F frames go through each barrier round together: 3 barriers per
-//      round instead of per frame, F times the work between them.
+// ---- per (window, band): 12 phase-difference planes from the frame planes.
+//   A  every frame's B plane and wrap flags are requested up front (26 independent loads per thread, one latency instead of one
+//      per barrier round); the flags are summed bytewise in one register per frame (k <= 12 per pixel), the difference planes start
+//      as B_i - B_{i-1}, and the workgroup agrees on the first frame in which ANY of its pixels has wrapped (one LDS min, one barrier)
+//   B  from that frame on, F frames per barrier round: blur(mag * (-2 pi k)) * R, whose frame-to-frame change is added to the planes.
+//      Frames before it have blur(mag * 0) = 0: rounds that end before the first wrap are skipped (always the window's first frame,
+//      whole windows of slowly moving faces)
+//   C  spatial means, clamp, store.  NHWC pixels take 48 of their 96 bytes from this band: the rows go through LDS so that three
+//      consecutive lanes write the 48 contiguous bytes of a pixel (a lane-per-pixel-strip store issues 64 separate 16-byte requests
+//      per instruction: 0.16 of the 0.61 ms these kernels took)
 #ifndef MM_PHASE_FPR
 #define MM_PHASE_FPR 3      // frames per barrier round
 #endif
@@ -147,10 +154,15 @@ phase_window2_kernel(const float* __restrict__ fr, const int32_t* __restrict__ i
                      int out_cstride, int out_coffset) {
     using C = Cfg<W>;
     constexpr int F = MM_PHASE_FPR;
-    __shared__ __attribute__((aligned(16))) float lds[F * (C::IN_PLANE + C::TMP_PLANE) + 64 * (P - 1)];
+    constexpr int RPG = W == 48 ? 16 : 12;                    // rows per store group: RPG * W * 12 floats staged at a time
+    constexpr int G = W / RPG;
+    constexpr int WORK = F * (C::IN_PLANE + C::TMP_PLANE);
+    static_assert(RPG * W * (P - 1) <= WORK, "store staging fits the blur planes");
+    __shared__ __attribute__((aligned(16))) float lds[WORK + 64 * (P - 1)];
+    __shared__ int first_wrap;
     float* in_x = lds;                              // [F][IN_PLANE]
     float* tmp_x = in_x + F * C::IN_PLANE;          // [F][TMP_PLANE]
-    float* red = tmp_x + F * C::TMP_PLANE;
+    float* red = lds + WORK;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // consecutive windows share 12 of their 13 frames: keep them on one XCD (one L2) instead of spreading them over all eight
     const int logical = xcd_contiguous(blockIdx.x, gridDim.x);
@@ -160,111 +172,114 @@ phase_window2_kernel(const float* __restrict__ fr, const int32_t* __restrict__ i
     const int y = active ? tid / C::STRIPS : 0;
     const int x0 = active ? (tid - y * C::STRIPS) * PX : 0;
     const int px = y * W + x0;
-    for (int i = tid; i < F * (C::IN_PLANE + C::TMP_PLANE); i += C::NTHREADS) lds[i] = 0.f;
-    __syncthreads();
-    const float PI_F = 3.14159265358979323846f, TWO_PI_F = 6.28318530717958647692f;
-    float kacc[PX] = {0.f, 0.f, 0.f, 0.f}, prev_out[PX], d[P - 1][PX], part[P - 1];
+    for (int i = tid; i < WORK; i += C::NTHREADS) lds[i] = 0.f;    // the zero rows above / below tmp_x
+    if (tid == 0) first_wrap = P;
+    const float TWO_PI_F = 6.28318530717958647692f, PI_F = 3.14159265358979323846f;
+    // ---- A
+    const float* fo[P];
+    float d[P - 1][PX];
+    unsigned kb[P];
+    {
+        float4 bprev = {0.f, 0.f, 0.f, 0.f};
+        int prev_id = -1;
+        unsigned run = 0;
 #pragma unroll
-    for (int k = 0; k < P - 1; ++k) part[k] = 0.f;
-    int prev_id = -1;
+        for (int i = 0; i < P; ++i) {
+            const int id = ids[j * P + i];
+            fo[i] = fr + ((int64_t)id * 2 + band) * C::FRAME_FLOATS;
+            float4 b4 = {0.f, 0.f, 0.f, 0.f};
+            if (active) {
+                b4 = *reinterpret_cast<const float4*>(fo[i] + C::PLANE + px);
+                // a new frame: its wrap flags refer to the frame before it, which is prev_id (a repeated edge frame has dd = 0)
+                if (i > 0 && id != prev_id) run += reinterpret_cast<const unsigned*>(fo[i] + 3 * C::PLANE)[px / 4];
+            }
+            kb[i] = run;
+            if (i > 0) {
+                d[i - 1][0] = b4.x - bprev.x; d[i - 1][1] = b4.y - bprev.y; d[i - 1][2] = b4.z - bprev.z; d[i - 1][3] = b4.w - bprev.w;
+            }
+            bprev = b4;
+            prev_id = id;
+        }
+    }
+    {
+        int mine = P;                     // first frame in which one of this thread's pixels has wrapped (counts only grow)
+#pragma unroll
+        for (int i = P - 1; i >= 0; --i) mine = kb[i] != 0u ? i : mine;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) mine = min(mine, __shfl_xor(mine, off, 64));
+        __syncthreads();                  // first_wrap initialised, LDS zeroed
+        if (lane == 0 && mine < P) atomicMin(&first_wrap, mine);
+        __syncthreads();
+    }
+    const int first = first_wrap;
+    // ---- B
+    float cprev[PX] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int base = 0; base < P; base += F) {
-        float4 b4[F], r4[F];
-        const float* fo[F];
-        int nz = 0;
+        if (base + F <= first) continue;             // block-uniform: no pixel of the window has wrapped up to the round's last frame
+        float4 r4[F];
 #pragma unroll
         for (int f = 0; f < F; ++f) {
             const int i = base + f;
-            b4[f] = r4[f] = float4{0.f, 0.f, 0.f, 0.f};
-            fo[f] = fr;
-            if (i >= P) continue;
-            const int id = ids[j * P + i];
-            const float* o = fr + ((int64_t)id * 2 + band) * C::FRAME_FLOATS;
-            fo[f] = o;
-            if (active) {
-                b4[f] = *reinterpret_cast<const float4*>(o + C::PLANE + px);
-                if (i > 0 && id != prev_id) {      // a new frame: its wrap flags refer to the frame before it, which is prev_id
-                    const unsigned wb = reinterpret_cast<const unsigned*>(o + 3 * C::PLANE)[px / 4];
-                    kacc[0] += (float)(wb & 1u); kacc[1] += (float)((wb >> 8) & 1u);
-                    kacc[2] += (float)((wb >> 16) & 1u); kacc[3] += (float)((wb >> 24) & 1u);
-                }
-                if ((kacc[0] + kacc[1] + kacc[2] + kacc[3]) != 0.f) {
-                    nz = 1;
-                    const float4 m4 = *reinterpret_cast<const float4*>(o + px);
-                    *reinterpret_cast<float4*>(in_x + f * C::IN_PLANE + px) =
-                        float4{m4.x * (-TWO_PI_F * kacc[0]), m4.y * (-TWO_PI_F * kacc[1]), m4.z * (-TWO_PI_F * kacc[2]),
-                               m4.w * (-TWO_PI_F * kacc[3])};
-                } else {
-                    *reinterpret_cast<float4*>(in_x + f * C::IN_PLANE + px) = float4{0.f, 0.f, 0.f, 0.f};
-                }
-            }
-            prev_id = id;
+            r4[f] = float4{0.f, 0.f, 0.f, 0.f};
+            if (i >= P || !active) continue;
+            const float4 m4 = *reinterpret_cast<const float4*>(fo[i] + px);
+            r4[f] = *reinterpret_cast<const float4*>(fo[i] + 2 * C::PLANE + px);    // a pixel's blur also sums its neighbours' wraps
+            const unsigned k = kb[i];
+            *reinterpret_cast<float4*>(in_x + f * C::IN_PLANE + px) =
+                float4{m4.x * (-TWO_PI_F * (float)(k & 255u)), m4.y * (-TWO_PI_F * (float)((k >> 8) & 255u)),
+                       m4.z * (-TWO_PI_F * (float)((k >> 16) & 255u)), m4.w * (-TWO_PI_F * (float)(k >> 24))};
         }
-        float s[F][PX];
+        __syncthreads();
+        if (active) {
 #pragma unroll
-        for (int f = 0; f < F; ++f) s[f][0] = s[f][1] = s[f][2] = s[f][3] = 0.f;
-        // no pixel of this window has wrapped up to the last frame of the round: blur(mag * 0) = 0, the ratios are the frames' own B
-        if (__syncthreads_or(nz)) {
-            if (active) {
-#pragma unroll
-                for (int f = 0; f < F; ++f) {
-                    if (base + f >= P) continue;
-                    r4[f] = *reinterpret_cast<const float4*>(fo[f] + 2 * C::PLANE + px);   // a pixel's blur also sums its neighbours' wraps
-                    float h[PX];
-                    row_pass<W>(in_x + f * C::IN_PLANE, y, x0, h);
-                    *reinterpret_cast<float4*>(tmp_x + f * C::TMP_PLANE + (y + R) * W + x0) = float4{h[0], h[1], h[2], h[3]};
-                }
+            for (int f = 0; f < F; ++f) {
+                if (base + f >= P) continue;
+                float h[PX];
+                row_pass<W>(in_x + f * C::IN_PLANE, y, x0, h);
+                *reinterpret_cast<float4*>(tmp_x + f * C::TMP_PLANE + (y + R) * W + x0) = float4{h[0], h[1], h[2], h[3]};
             }
-            __syncthreads();
-            if (active) {
-#pragma unroll
-                for (int f = 0; f < F; ++f) {
-                    if (base + f >= P) continue;
-                    col_pass<W>(tmp_x + f * C::TMP_PLANE, y, x0, s[f]);
-                }
-            }
-            // (the next round's in_x stores are separated from this round's row-pass reads by the barrier above, its tmp_x stores
-            //  from these column reads by its own __syncthreads_or)
         }
+        __syncthreads();
+        // (the next round's in_x stores are separated from this round's row-pass reads by the barrier above, its tmp_x stores from
+        //  the column reads below by its own first barrier)
         if (active) {
 #pragma unroll
             for (int f = 0; f < F; ++f) {
                 const int i = base + f;
                 if (i >= P) continue;
-                const float o4[PX] = {fmaf(s[f][0], r4[f].x, b4[f].x), fmaf(s[f][1], r4[f].y, b4[f].y), fmaf(s[f][2], r4[f].z, b4[f].z),
-                                      fmaf(s[f][3], r4[f].w, b4[f].w)};
+                float sb[PX];
+                col_pass<W>(tmp_x + f * C::TMP_PLANE, y, x0, sb);
+                const float c[PX] = {sb[0] * r4[f].x, sb[1] * r4[f].y, sb[2] * r4[f].z, sb[3] * r4[f].w};
 #pragma unroll
                 for (int p = 0; p < PX; ++p) {
-                    if (i > 0) {
-                        d[i - 1][p] = o4[p] - prev_out[p];
-                        part[i - 1] += d[i - 1][p];
-                    }
-                    prev_out[p] = o4[p];
+                    if (i > 0) d[i - 1][p] += c[p] - cprev[p];
+                    cprev[p] = c[p];
                 }
             }
         }
     }
-    // ---- spatial means of the 12 difference planes: wave shuffle reduce, then across waves
+    // ---- C: spatial means of the 12 difference planes: wave shuffle reduce, then across waves
 #pragma unroll
     for (int k = 0; k < P - 1; ++k) {
-        float v = active ? part[k] : 0.f;
+        float v = active ? (d[k][0] + d[k][1]) + (d[k][2] + d[k][3]) : 0.f;
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
         if (lane == 0) red[wave * (P - 1) + k] = v;
     }
-    __syncthreads();
+    __syncthreads();                      // also: every blur read of the planes is done, they become the store staging
     constexpr int NWAVES = C::NTHREADS / 64;
     const float LIM = 5.f * PI_F;
-    if (active) {
-        float mean[P - 1];
+    float mean[P - 1];
 #pragma unroll
-        for (int k = 0; k < P - 1; ++k) {
-            float sm = 0.f;
+    for (int k = 0; k < P - 1; ++k) {
+        float sm = 0.f;
 #pragma unroll
-            for (int w = 0; w < NWAVES; ++w) sm += red[w * (P - 1) + k];
-            mean[k] = sm * (1.0f / (W * W));
-        }
-        if (!out_nhwc) {
+        for (int w = 0; w < NWAVES; ++w) sm += red[w * (P - 1) + k];
+        mean[k] = sm * (1.0f / (W * W));
+    }
+    if (!out_nhwc) {
+        if (active) {
 #pragma unroll
             for (int k = 0; k < P - 1; ++k) {
                 float ov[PX];
@@ -273,10 +288,15 @@ phase_window2_kernel(const float* __restrict__ fr, const int32_t* __restrict__ i
                 float* dst = out + ((j * (2 * (P - 1)) + band * (P - 1) + k) * W + y) * W + x0;
                 *reinterpret_cast<float4*>(dst) = float4{ov[0], ov[1], ov[2], ov[3]};
             }
-        } else {
+        }
+        return;
+    }
+    float4* stage = reinterpret_cast<float4*>(lds);      // [RPG * W pixels][3 float4]
 #pragma unroll
-            for (int p = 0; p < PX; ++p) {
-                float* dst = out + ((j * W + y) * W + x0 + p) * out_cstride + out_coffset + band * (P - 1);
+    for (int g = 0; g < G; ++g) {
+        if (active && y / RPG == g) {
+#pragma unroll
+            for (int p = 0; p < PX; ++p)
 #pragma unroll
                 for (int q = 0; q < (P - 1) / 4; ++q) {
                     float4 v;
@@ -284,10 +304,16 @@ phase_window2_kernel(const float* __restrict__ fr, const int32_t* __restrict__ i
                     v.y = fminf(fmaxf(d[4 * q + 1][p] - mean[4 * q + 1], -LIM), LIM);
                     v.z = fminf(fmaxf(d[4 * q + 2][p] - mean[4 * q + 2], -LIM), LIM);
                     v.w = fminf(fmaxf(d[4 * q + 3][p] - mean[4 * q + 3], -LIM), LIM);
-                    reinterpret_cast<float4*>(dst)[q] = v;
+                    stage[((y - g * RPG) * W + x0 + p) * 3 + q] = v;
                 }
-            }
         }
+        __syncthreads();
+        for (int idx = tid; idx < RPG * W * 3; idx += C::NTHREADS) {
+            const int pix = idx / 3, part = idx - pix * 3;
+            float* dst = out + ((j * W + g * RPG) * W + pix) * out_cstride + out_coffset + band * (P - 1) + part * 4;
+            *reinterpret_cast<float4*>(dst) = stage[idx];
+        }
+        if (g + 1 < G) __syncthreads();
     }
 }
 

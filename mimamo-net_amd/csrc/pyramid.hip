@@ -17,7 +17,7 @@
 //   * the hi-pass and low-pass residual IFFTs (SCFpyr_PyTorch.py:120-124,132-135) are never used by
 //     inference and are not computed.
 // All products run on the fp32 matrix cores (v_mfma_f32_16x16x4_f32: exact fp32 FMA chains), one
-// 256-thread workgroup per (frame, band), operands staged in LDS with bank-conflict-free strides.
+// 256-thread workgroup per frame (both bands off one DCT), operands staged in LDS with bank-conflict-free strides.
 #include "mm_common.h"
 #include "phase_math.h"
 
@@ -224,7 +224,7 @@ __device__ __forceinline__ void band_pass(float* lds, const float* __restrict__ 
     __syncthreads();
 }
 
-// grid-stride over work items (frame, band); tables are loaded into LDS once per workgroup.
+// grid-stride over frames; both bands of a frame share its DCT (x -> T1 -> G); tables are loaded into LDS once per workgroup.
 __global__ void __launch_bounds__(NT)
 pyramid_kernel(const float* __restrict__ tables, const float* __restrict__ frames, int64_t n, int64_t group,
                float* __restrict__ c1, int64_t group_stride1, int64_t img_stride1, int64_t band_stride1,
@@ -238,9 +238,7 @@ pyramid_kernel(const float* __restrict__ tables, const float* __restrict__ frame
         lds[L_ES + i] = tables[OFF_ES + i];
     }
     const float* dct = lds + L_DCT;
-    for (int64_t item = blockIdx.x; item < 2 * n; item += gridDim.x) {
-        const int64_t img = item >> 1;
-        const int band = (int)(item & 1);
+    for (int64_t img = blockIdx.x; img < n; img += gridDim.x) {
         // ---- x -> LDS
         {
             const float4* src = reinterpret_cast<const float4*>(frames + img * (S * S));
@@ -276,15 +274,12 @@ pyramid_kernel(const float* __restrict__ tables, const float* __restrict__ frame
         __syncthreads();
         // output plane of (img, band): images come in groups of `group` (one window on the drop-in path)
         const int64_t grp = img / group, pos = img - grp * group;
-        float* o1 = c1 + grp * group_stride1 + pos * img_stride1 + band * band_stride1;
-        float* o2 = c2 + grp * group_stride2 + pos * img_stride2 + band * band_stride2;
-        if (band == 0) {
-            band_pass<48, 0>(lds, tables + OFF_M1B0, o1, polar);
-            band_pass<24, 0>(lds, tables + OFF_M2B0, o2, polar);
-        } else {
-            band_pass<48, 1>(lds, tables + OFF_M1B1, o1, polar);
-            band_pass<24, 1>(lds, tables + OFF_M2B1, o2, polar);
-        }
+        float* o1 = c1 + grp * group_stride1 + pos * img_stride1;
+        float* o2 = c2 + grp * group_stride2 + pos * img_stride2;
+        band_pass<48, 0>(lds, tables + OFF_M1B0, o1, polar);
+        band_pass<24, 0>(lds, tables + OFF_M2B0, o2, polar);
+        band_pass<48, 1>(lds, tables + OFF_M1B1, o1 + band_stride1, polar);
+        band_pass<24, 1>(lds, tables + OFF_M2B1, o2 + band_stride2, polar);
     }
 }
 
@@ -296,7 +291,7 @@ int launch_pyramid(const mm_pyramid* h, const float* frames, int64_t n, int64_t 
     // per launch (microseconds): the attribute belongs to the current device's copy of the kernel
     MM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(pyramid_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                lds_bytes));
-    int64_t grid = 2 * n;
+    int64_t grid = n;
     if (grid > 1024) grid = 1024;  // 256 CUs x 1 resident workgroup; the rest grid-strides
     prof_before(1, (double)n * (S * S * 4), stream);  // algorithmic read of the stage: one fp32 frame
     hipLaunchKernelGGL(pyramid_kernel, dim3((unsigned)grid), dim3(NT), lds_bytes, stream, h->d_tables, frames, n,
