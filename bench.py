@@ -186,7 +186,10 @@ class HipCompute(object):
         ids = sorted(set(int(c) for c in content_ids))
         self.pool = {c: i for i, c in enumerate(ids)}
         clips = [synthetic.make_clip_u8(c, FRAMES_PER_CLIP) for c in ids]
-        self.frames_u8 = torch.from_numpy(np.concatenate(clips)).to(self.device)
+        from mimamo_net_amd import stream as mstream
+        self.frames_host = mstream.pin(np.concatenate(clips))           # the raw boundary in page-locked host memory
+        self.frames_u8 = self.frames_host.to(self.device)
+        self._fs = None
         if self.args.from_f32:
             g, r = zip(*[synthetic.preprocess_host(c) for c in clips])
             self.pre = (torch.from_numpy(np.concatenate(g)).to(self.device), torch.from_numpy(np.concatenate(r)).to(self.device))
@@ -209,11 +212,47 @@ class HipCompute(object):
         srcs = self.pre if self.args.from_f32 else (self.frames_u8,)
         return srcs if sel is False else tuple(t.index_select(0, sel) for t in srcs)
 
+    def _host_pieces(self, content_ids):
+        """Pinned host views of the step's clips, adjacent pool slots merged into one copy."""
+        runs, F = [], FRAMES_PER_CLIP
+        for c in content_ids:
+            slot = self.pool[c]
+            if runs and runs[-1][1] == slot:
+                runs[-1][1] = slot + 1
+            else:
+                runs.append([slot, slot + 1])
+        return [self.frames_host[a * F:b * F] for a, b in runs]
+
+    def step_streamed(self, content_ids, next_ids=None, lanes=None):
+        """The same step with its uint8 frames coming from pinned HOST memory: a dedicated copy stream uploads the NEXT step's
+        frames into the other half of a double buffer while this step computes (stream.FrameStream); the compute streams only
+        wait for the upload event of their own buffer.  Same rows as step(), bit for bit."""
+        from mimamo_net_amd.stream import FrameStream
+        rows = len(content_ids) * FRAMES_PER_CLIP
+        if self._fs is None or self._fs.slots[0].shape[0] < rows:
+            self._fs = FrameStream(self.device, max(rows, self.args.clips * FRAMES_PER_CLIP))
+            self._fs_next = 0
+        fs = self._fs
+        key = tuple(content_ids)
+        slot = fs.find(("step", key))
+        if slot is None:                                  # cold start: nothing was prefetched for this step
+            slot = self._fs_next
+            fs.upload(slot, self._host_pieces(content_ids), ("step", key))
+        if next_ids:
+            fs.upload(1 - slot, self._host_pieces(next_ids), ("step", tuple(next_ids)))
+        self._fs_next = 1 - slot
+        frames = fs.acquire(slot)
+        out = self._forward((frames,), len(content_ids), self.args.lanes if lanes is None else lanes, True)
+        fs.release(slot)
+        return out
+
     def step(self, content_ids, lanes=None):
         ins = self._select(content_ids)
-        lengths = [FRAMES_PER_CLIP] * len(content_ids)
         lanes = self.args.lanes if lanes is None else lanes
-        u8 = not self.args.from_f32
+        return self._forward(ins, len(content_ids), lanes, not self.args.from_f32)
+
+    def _forward(self, ins, n_clips, lanes, u8):
+        lengths = [FRAMES_PER_CLIP] * n_clips
         if lanes > 1:
             return self.hot.forward_lanes(ins, lengths, lanes, independent_clips=True, from_u8=u8)
         plan = self.hot.plan(lengths) if getattr(self, "_plan_n", None) != len(lengths) else self._plan
@@ -222,6 +261,9 @@ class HipCompute(object):
 
     def sync(self):
         torch.cuda.synchronize()
+
+    def sync_compute(self):
+        torch.cuda.current_stream().synchronize()      # lanes have been joined into the current stream by forward_lanes
 
 
 class StubCompute(object):
@@ -240,6 +282,9 @@ class StubCompute(object):
         return torch.stack([c, f], -1).reshape(-1, 2).contiguous()
 
     def sync(self):
+        pass
+
+    def sync_compute(self):
         pass
 
 
@@ -274,6 +319,9 @@ def parse_args(argv=None):
                     help="start every step from host-preprocessed fp32 tensors (gray 48x48, RGB 224x224) instead of the "
                          "raw uint8 boundary")
     ap.add_argument("--from-u8", action="store_true", help="(default) start every step from uint8 112x112x3 frames in HBM")
+    ap.add_argument("--stream-input", action="store_true",
+                    help="every timed step takes its uint8 frames from pinned host memory through a copy stream, double-buffered "
+                         "against compute (the headline keeps inputs resident in HBM; the default line reports this as extra.streamed)")
     ap.add_argument("--cpu-clips", type=int, default=16, help="64-frame clips timed on the host for cpu_baseline (all processes together)")
     return ap.parse_args(argv)
 
@@ -318,7 +366,9 @@ def run_rank(args):
     # ---- the work queue: rank 0 builds it, everyone receives it (RCCL broadcast), everyone shards it the same way
     total = args.total_clips or (10000 if world > 1 else args.clips)
     work0 = np.stack([np.arange(total), np.full(total, FRAMES_PER_CLIP)], 1) if rank == 0 else None
+    t_b = time.perf_counter()
     work = mdist.broadcast_work(work0, rank, world, coll_dev)
+    bcast_ms = (time.perf_counter() - t_b) * 1e3     # first collective of the job: includes RCCL's communicator set-up
     assert work.shape == (total, 2) and (work[:, 1] == FRAMES_PER_CLIP).all()
     mine = [int(work[i, 0]) for i in mdist.shard(total, rank, world)]          # clip ids of this rank, queue order
     if not mine:
@@ -337,7 +387,9 @@ def run_rank(args):
     content = lambda ids: [c % distinct for c in ids]                         # noqa: E731
 
     comp = (StubCompute if args.stub_compute else HipCompute)(args, device)
+    t_l = time.perf_counter()
     comp.load({c % distinct for s in warm + timed for c in s})
+    load_s = time.perf_counter() - t_l
 
     # The [frames,2] results of a step are all-gathered (8 B/frame, the only collective besides the queue broadcast).  It
     # is issued asynchronously on RCCL's stream and only waited for one step later, so a rank never stalls on a slower
@@ -352,8 +404,13 @@ def run_rank(args):
                 h.wait()
             last["gathered"] = bufs
 
-    def step(ids):
-        out = comp.step(content(ids)) if ids else torch.zeros((0, 2), device=device)
+    def step(ids, nxt=None):
+        if not ids:
+            out = torch.zeros((0, 2), device=device)
+        elif args.stream_input and gpu:
+            out = comp.step_streamed(content(ids), content(nxt) if nxt else None)
+        else:
+            out = comp.step(content(ids))
         if world > 1 or args.force_dist:
             drain()
             rows = args.clips * FRAMES_PER_CLIP
@@ -375,14 +432,19 @@ def run_rank(args):
         comp.sync()
 
     with torch.no_grad():
-        for ids in warm:
-            out = step(ids)
+        for i, ids in enumerate(warm):
+            out = step(ids, (warm + timed)[i + 1] if i + 1 < len(warm) + len(timed) else None)
         fence()
         t0 = time.perf_counter()
-        for ids in timed:
-            out = step(ids)
+        for i, ids in enumerate(timed):
+            out = step(ids, timed[i + 1] if i + 1 < len(timed) else None)
+        # this rank's own finish time (its compute stream only: the result all-gather runs on RCCL's stream and the barrier
+        # below waits for the slowest peer) -- reported per rank so a poor scaling number can be attributed
+        comp.sync_compute()
+        dt_local = time.perf_counter() - t0
         fence()
         dt = time.perf_counter() - t0
+    dt_own = dt
     dt = mdist.max_over_ranks(dt, coll_dev)
     frames_rank = sum(len(s) for s in timed) * FRAMES_PER_CLIP
     frames_all = total * FRAMES_PER_CLIP if args.whole_job else world * frames_rank
@@ -412,13 +474,23 @@ def run_rank(args):
                                if not args.from_f32 else
                                ("full two-stream hot path (BASELINE configs[3]) from host-preprocessed fp32 tensors (gray 48x48 + "
                                 "RGB 224x224): %d clips x 64 frames per GPU per step" % per_step),
-                   "input": "preprocessed fp32 tensors" if args.from_f32 else "uint8 112x112x3 frames",
+                   "input": "preprocessed fp32 tensors" if args.from_f32 else
+                            ("uint8 112x112x3 frames streamed from pinned host memory (copy stream, double-buffered)" if args.stream_input
+                             else "uint8 112x112x3 frames"),
                    "lanes": args.lanes, "clips_per_gpu": per_step, "frames_per_step_per_gpu": n_frames,
                    "work_queue": {"total_clips": total, "clips_this_rank": len(mine), "distinct_clip_contents": distinct,
                                   "broadcast": backend if (world > 1 or args.force_dist) else None,
                                   "whole_job": bool(args.whole_job)},
                    "parallelism": "videos sharded, dp%d" % world},
     }
+    if world > 1 or args.force_dist:
+        # one row per rank, gathered with the collective the results use: enough to tell a slow rank (ms_per_step_local), a
+        # rank held up by its peers (ms_per_step >> local) or a slow communicator set-up (queue_broadcast_ms) apart
+        rows = mdist.all_gather_floats([rank, dt_local / max(n_steps, 1) * 1e3, dt_own / max(n_steps, 1) * 1e3, frames_rank,
+                                        bcast_ms, load_s, dev_index if gpu else -1], coll_dev)
+        result["per_rank"] = [{"rank": int(r[0]), "ms_per_step_local": r[1], "ms_per_step": r[2], "frames": int(r[3]),
+                               "queue_broadcast_ms": r[4], "input_load_s": r[5], "device": int(r[6])} for r in rows]
+        result["config"]["work_queue"]["broadcast_ms_rank0"] = bcast_ms if rank == 0 else None
     if args.stub_compute:
         if rank == 0:
             print(json.dumps(result))
@@ -445,26 +517,29 @@ def run_rank(args):
     phase_ms = ms[1] + ms[2]
     phase_gbs = (work_[1] + work_[2]) / (phase_ms * 1e-3) / 1e9
 
-    def committed_traffic(name):
-        """PMC HBM traffic from profiles/ -- only if it was measured on these kernels at this step size."""
-        path = os.path.join(ROOT, "profiles", name % per_step)
-        if not os.path.exists(path):
-            return None
-        with open(path) as f:
-            tj = json.load(f)
-        if tj.get("kernel_source_hash") != kernel_source_hash() or tj.get("clips_per_gpu") != per_step:
-            return None
-        return tj.get("bytes_per_step")
+    def committed_traffic(kind):
+        """PMC HBM traffic from profiles/*<kind>_traffic*.json -- whichever summary was measured on THESE kernel sources (hash)
+        at this step size; file names (rounds) do not matter.  None when the kernels changed since the last PMC run."""
+        import glob
+        for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*%s_traffic*.json" % kind)), reverse=True):
+            try:
+                with open(path) as f:
+                    tj = json.load(f)
+            except (OSError, ValueError):
+                continue
+            if tj.get("kernel_source_hash") == kernel_source_hash() and tj.get("clips_per_gpu") == per_step:
+                return tj.get("bytes_per_step"), os.path.basename(path)
+        return None, None
 
-    traffic = committed_traffic("r02_conv_traffic_%dclips.json")
-    ptraffic = committed_traffic("r02_phase_traffic_%dclips.json")
+    traffic, traffic_file = committed_traffic("conv")
+    ptraffic, ptraffic_file = committed_traffic("phase")
     wino = 0 if args.no_winograd else {1: "F(4x4,3x3); output transform fused into the GEMMs for Cin <= 256", 2: "F(2x2,3x3)", 4: "F(4x4,3x3), three kernels", 5: "F(4x4,3x3), fused everywhere"}.get(args.winograd, args.winograd)
     result["roofline"] = {
         "bound": "mfma", "kernel": "conv_mfma_kernel (fp32 implicit-GEMM conv/GEMM engine, all %d launches of one step)" % launches[0],
         "achieved": conv_tflops, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
         "frac": conv_tflops / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic,
         "traffic_note": ("HBM bytes per step over all conv launches, rocprofv3 PMC (2*FETCH_SIZE + WRITE_SIZE)*1024, from "
-                         "profiles/ (same kernel sources, not live)") if traffic else
+                         "profiles/%s (same kernel sources, not live)" % traffic_file) if traffic else
                         "no PMC summary under profiles/ for these kernel sources (hash %s)" % kernel_source_hash(),
         "flops_per_step": work_[0], "ms_per_step": ms[0], "launches_per_step": int(launches[0]),
         "note": "flops = executed on the matrix cores; with Winograd F(4x4,3x3) (or F(2x2,3x3)) on the stride-1 3x3 layers of conv2_x..conv5_x "
@@ -476,9 +551,9 @@ def run_rank(args):
         "winograd": wino,
         "winograd_transforms": {"ms_per_step": ms[3], "bytes_per_step": work_[3], "launches_per_step": int(launches[3]),
                                 "GB_per_s": (work_[3] / (ms[3] * 1e-3) / 1e9) if ms[3] > 0 else None}}
-    result["roofline_phase"] = {"bound": "hbm", "kernel": "pyramid_kernel + phase_window_kernel<48|24>",
+    result["roofline_phase"] = {"bound": "hbm", "kernel": "pyramid_frame_kernel + phase_window2_kernel<48|24> (all phase-stage launches of one step)",
                                 "achieved": phase_gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": phase_gbs / PEAK_HBM_GBS,
-                                "traffic": ptraffic, "bytes_per_step": work_[1] + work_[2], "ms_per_step": phase_ms,
+                                "traffic": ptraffic, "traffic_file": ptraffic_file, "bytes_per_step": work_[1] + work_[2], "ms_per_step": phase_ms,
                                 "ms_pyramid": ms[1], "ms_window": ms[2]}
 
     if rank == 0 and world == 1 and not args.no_extra:
@@ -524,6 +599,25 @@ def extra_legs(args, comp, ids0, n_frames):
     hot.resnet.set_winograd(wino)
     ex["direct_form"] = {"value": n_frames / dt, "unit": "frames/s", "ms_per_step": dt * 1e3,
                          "what": "same step with every 3x3 layer as a direct implicit GEMM (no Winograd)"}
+    # (a2) the headline step with its input streamed over PCIe instead of resident in HBM
+    if not args.from_f32:
+        seq = [ids0] * (K + 1)
+        with torch.no_grad():
+            comp.step_streamed(seq[0], seq[1])
+            torch.cuda.synchronize()
+            b0 = comp._fs.bytes_uploaded
+            t0 = time.perf_counter()
+            for i in range(K):
+                comp.step_streamed(seq[i + 1], seq[i + 2] if i + 2 <= K else None)
+            torch.cuda.synchronize()
+            dts = (time.perf_counter() - t0) / K
+            up = (comp._fs.bytes_uploaded - b0) / K
+        dtr = timeit(lambda: comp.step(ids0))
+        ex["streamed"] = {"value": n_frames / dts, "unit": "frames/s", "ms_per_step": dts * 1e3,
+                          "resident_value": n_frames / dtr, "resident_ms_per_step": dtr * 1e3, "streamed_over_resident": dtr / dts,
+                          "pcie_bytes_per_step": up, "pcie_GB_per_s": up / dts / 1e9,
+                          "what": "same step, uint8 frames uploaded from pinned host memory on a copy stream while the previous step "
+                                  "computes (double buffer); resident_* = the headline form measured back to back in this leg"}
     # (b) multi-snippet videos
     nv = max(1, round(n_frames / EXAMPLE_VIDEO_FRAMES))
     vids = torch.from_numpy(np.concatenate([synthetic.make_clip_u8(5000 + v, EXAMPLE_VIDEO_FRAMES) for v in range(nv)])).to(comp.device)

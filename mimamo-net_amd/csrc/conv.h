@@ -55,6 +55,8 @@ int wino_output_transform(const float* M, const float* bias, float* y, int B, in
 // Needs Cin % 64 == 0 and Cout % 32 == 0 (MM_ERR_UNSUPPORTED otherwise).
 int wino_gemm_output_fused(const float* V, const float* U, const float* bias, float* y, int B, int H, int W, int Cin, int Cout,
                            int relu, int shape, hipStream_t s);
+// whether wino_gemm_output_fused takes the shape (channel granularity, 32-bit offsets inside a position plane)
+bool wino_fused_supported(int64_t ntile, int Cin, int Cout);
 
 // one GRU time step for a batch of Bt rows (PyTorch gate order r,z,n):
 //   gi [Bt, gi_stride] (+gi_off) = W_ih x + b_ih ; gh [Bt, 3H] = W_hh h + b_hh (or null with bhh => h == 0)

@@ -222,6 +222,8 @@ static int run_layer_wino(const Layer& L, const float* in, int B, int H, int W, 
     if (fused) m = 4;
     const int wc = L.wino_cin;          // K of the position GEMMs (= cin unless the layer was built with zero-padded columns)
     if (wc != L.cin_p && m != 4) return MM_ERR_UNSUPPORTED;
+    // no plane set for the three-kernel form and the fused kernel declines the shape: say so before transforming anything
+    if (!M && !(fused && wino_fused_supported(ntile, wc, L.cout))) return MM_ERR_UNSUPPORTED;
     int rc = wino_input_transform(in, V, B, H, W, wc, m, s, L.cin_p);
     if (rc != MM_OK) return rc;
     if (fused) {
@@ -642,12 +644,13 @@ namespace {
 struct HeadWs {
     int64_t p0n, a0, cat, a1, a2, a3, a4, pool, fc1, m1, feat, f, gi, gh, l0, l1, wv;
 };
-HeadWs head_sizes(int64_t N, int64_t T, int64_t mlp_max) {
+HeadWs head_sizes(int64_t N, int64_t T, int64_t mlp_max, bool wino) {
     HeadWs s;
     s.p0n = N * 48 * 48 * 24; s.a0 = N * 48 * 48 * 64; s.cat = N * 24 * 24 * 88; s.a1 = N * 24 * 24 * 128;
     s.a2 = N * 12 * 12 * 128; s.a3 = N * 12 * 12 * 256; s.a4 = N * 6 * 6 * 256; s.pool = N * 256; s.fc1 = N * 256;
     s.m1 = 2 * N * mlp_max; s.feat = N * 512; s.f = N * 256; s.gi = N * 768; s.gh = T * 384; s.l0 = N * 256; s.l1 = N * 256;
-    s.wv = N * 36 * 36 * 128;   // Winograd planes of the 24x24 layer (36 positions x 36 tiles x 128 channels); the 12x12 layer's fit too
+    // Winograd planes of the 24x24 layer (36 positions x 36 tiles x 128 channels); the 12x12 layer's fit too
+    s.wv = wino ? N * 36 * 36 * 128 : 0;
     return s;
 }
 }  // namespace
@@ -655,7 +658,7 @@ HeadWs head_sizes(int64_t N, int64_t T, int64_t mlp_max) {
 int64_t mm_head_workspace_bytes(mm_head_t* h, int64_t bs, int64_t T) {
     using mm::Bump;
     if (!h || bs < 0 || T < 0) return MM_ERR_INVALID_ARG;
-    const HeadWs s = head_sizes(bs * T, T, h->mlp_max);
+    const HeadWs s = head_sizes(bs * T, T, h->mlp_max, h->winograd != 0);
     const int64_t all[] = {s.p0n, s.a0, s.cat, s.a1, s.a2, s.a3, s.a4, s.pool, s.fc1, s.m1, s.feat, s.f, s.gi, s.gh, s.l0, s.l1, s.wv};
     int64_t tot = 0;
     for (int64_t v : all) tot += Bump::size_of(v);
@@ -673,7 +676,7 @@ int mm_head_forward(mm_head_t* h, const float* phase_0, const float* phase_1, in
     MM_CHECK_DEVICE(h);
     hipStream_t s = (hipStream_t)stream_;
     const int N = (int)N64;
-    const HeadWs z = head_sizes(N64, T, h->mlp_max);
+    const HeadWs z = head_sizes(N64, T, h->mlp_max, h->winograd != 0);
     Bump ws(workspace, workspace_bytes);
     float* p0n = ws.take(z.p0n); float* a0 = ws.take(z.a0); float* cat = ws.take(z.cat); float* a1 = ws.take(z.a1);
     float* a2 = ws.take(z.a2); float* a3 = ws.take(z.a3); float* a4 = ws.take(z.a4); float* pool = ws.take(z.pool);
@@ -699,17 +702,16 @@ int mm_head_forward(mm_head_t* h, const float* phase_0, const float* phase_1, in
     }
     MM_TRY(run_layer(h->conv[0], x0, N, 48, 48, 24, 0, a0, 64, 0, nullptr, 0, s));
     MM_TRY(run_layer(h->conv[1], a0, N, 48, 48, 64, 0, cat, 88, 0, nullptr, 0, s));
-    if (h->winograd && h->conv[2].wino_u4) {
-        MM_TRY(run_layer_wino(h->conv[2], cat, N, 24, 24, a1, wv, nullptr, 5, s));   // K = 88 padded to 128 with zero columns
-    } else {
-        MM_TRY(run_layer(h->conv[2], cat, N, 24, 24, 88, 0, a1, 128, 0, nullptr, 0, s));
-    }
+    // the fused Winograd kernel declines (MM_ERR_UNSUPPORTED) what its 32-bit plane offsets cannot address: direct form then
+    rc = MM_ERR_UNSUPPORTED;
+    if (h->winograd && h->conv[2].wino_u4) rc = run_layer_wino(h->conv[2], cat, N, 24, 24, a1, wv, nullptr, 5, s);   // K = 88 padded to 128
+    if (rc == MM_ERR_UNSUPPORTED) rc = run_layer(h->conv[2], cat, N, 24, 24, 88, 0, a1, 128, 0, nullptr, 0, s);
+    if (rc != MM_OK) return rc;
     MM_TRY(run_layer(h->conv[3], a1, N, 24, 24, 128, 0, a2, 128, 0, nullptr, 0, s));
-    if (h->winograd && h->conv[4].wino_u4) {
-        MM_TRY(run_layer_wino(h->conv[4], a2, N, 12, 12, a3, wv, nullptr, 5, s));   // 3x3 tiles per map
-    } else {
-        MM_TRY(run_layer(h->conv[4], a2, N, 12, 12, 128, 0, a3, 256, 0, nullptr, 0, s));
-    }
+    rc = MM_ERR_UNSUPPORTED;
+    if (h->winograd && h->conv[4].wino_u4) rc = run_layer_wino(h->conv[4], a2, N, 12, 12, a3, wv, nullptr, 5, s);   // 3x3 tiles per map
+    if (rc == MM_ERR_UNSUPPORTED) rc = run_layer(h->conv[4], a2, N, 12, 12, 128, 0, a3, 256, 0, nullptr, 0, s);
+    if (rc != MM_OK) return rc;
     MM_TRY(run_layer(h->conv[5], a3, N, 12, 12, 256, 0, a4, 256, 0, nullptr, 0, s));
     MM_TRY(avgpool_hw(a4, pool, N64, 36, 256, 256, 0, 0, s));
     MM_TRY(run_layer(h->fc1, pool, N, 1, 1, 256, 0, fc1, 256, 0, nullptr, 0, s));

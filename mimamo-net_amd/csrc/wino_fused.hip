@@ -331,16 +331,21 @@ static int launch_fused(WinoFusedParams p, hipStream_t s) {
     return MM_OK;
 }
 
+bool wino_fused_supported(int64_t ntile, int Cin, int Cout) {
+    if (Cin <= 0 || Cout <= 0 || Cin % 64 || Cout % 32) return false;
+    // 32-bit buffer offsets inside a position plane: larger problems are not an error, the caller takes another form
+    return (ntile + 64) * Cin * 4 < 0xFFFFF000ll && ((int64_t)Cout + 64) * Cin * 4 < 0xFFFFF000ll;
+}
+
 // V [36][ntile][Cin] (from wino_input_transform, m = 4), U [36][Cout][Cin] -> y NHWC [B,H,W,Cout] (+bias, ReLU)
 int wino_gemm_output_fused(const float* V, const float* U, const float* bias, float* y, int B, int H, int W, int Cin, int Cout,
                             int relu, int shape, hipStream_t s) {
-    if (Cin % 64 || Cout % 32) return MM_ERR_UNSUPPORTED;
     WinoFusedParams p;
     p.V = V; p.U = U; p.bias = bias; p.out = y;
     p.TH = (H + 3) / 4; p.TW = (W + 3) / 4;
     const int64_t ntile = (int64_t)B * p.TH * p.TW;
+    if (!wino_fused_supported(ntile, Cin, Cout)) return MM_ERR_UNSUPPORTED;
     if (ntile <= 0) return MM_OK;
-    if ((ntile + 64) * Cin * 4 >= 0xFFFFF000ll || ((int64_t)Cout + 64) * Cin * 4 >= 0xFFFFF000ll) return MM_ERR_INVALID_ARG;
     p.ntile = (int)ntile; p.K = Cin; p.Cout = Cout; p.B = B; p.H = H; p.W = W; p.relu = relu; p.tiles_n = 0;
     // shape: 0 = four-wave workgroups of 32 tiles x 64 channels, two per CU (default: measured 3-6 % faster than one eight-wave
     // workgroup per CU -- no common barrier between the two waves of a SIMD, prologue / epilogue of one workgroup under the

@@ -40,7 +40,9 @@ def init(backend=None, device_index=None, force=False):
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
         kw = {}
-        if torch.cuda.is_available():
+        # bind a GPU only where one is asked for: RCCL ranks (one per GPU), or an explicit device_index.  A gloo plumbing run
+        # on a GPU host with fewer GPUs than ranks (tests, --stub-compute) must not touch cuda:<local_rank>
+        if torch.cuda.is_available() and (backend == "nccl" or device_index is not None):
             torch.cuda.set_device(local_rank if device_index is None else device_index)
             if backend == "nccl":
                 kw["device_id"] = torch.device("cuda", torch.cuda.current_device())
@@ -141,6 +143,21 @@ def max_over_ranks(value, device="cpu"):
         t = t.cpu()
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
+
+
+def all_gather_floats(values, device="cpu"):
+    """Every rank contributes the same number of floats; returns a [world, k] float64 numpy array on every rank
+    (diagnostics: per-rank step times, frame counts)."""
+    v = np.asarray(values, dtype=np.float64).reshape(-1)
+    if not active():
+        return v[None, :].copy()
+    import torch.distributed as dist
+    t = torch.from_numpy(v.copy()).to(torch.device(device))
+    if _staged(t):
+        t = t.cpu()
+    bufs = [torch.empty_like(t) for _ in range(dist.get_world_size())]
+    dist.all_gather(bufs, t)
+    return torch.stack([b.cpu() for b in bufs], 0).numpy()
 
 
 def barrier():

@@ -23,10 +23,12 @@ from .resnet50_extractor import Resnet50_Extractor
 
 class HotPath(object):
     def __init__(self, head_state_dict, resnet_state_dict, device=None, length=64, stride=64, num_phase=12,
-                 batch_size=64, max_frames_per_call=4096):
+                 batch_size=64, max_frames_per_call=4096, upload_chunk_frames=1024):
         self.device = torch.device('cuda', torch.cuda.current_device()) if device is None else torch.device(device)
         self.length, self.stride, self.num_phase, self.batch_size = length, stride, num_phase, batch_size
         self.max_frames_per_call = int(max_frames_per_call)
+        self.upload_chunk_frames = max(1, int(upload_chunk_frames))   # host-resident input: frames per double-buffered upload
+        self._feeders = {}
         self.pde = Phase_Difference_Extractor(4, 2, 2, [1, 2], False)
         self.resnet = Resnet50_Extractor(state_dict=resnet_state_dict, device=self.device,
                                          max_frames_per_call=self.max_frames_per_call)
@@ -113,6 +115,8 @@ class HotPath(object):
         if self._pre is None:
             from .preprocess import FramePreprocessor
             self._pre = FramePreprocessor(device=self.device)
+        if not frames_u8.is_cuda:
+            return self._forward_u8_host(frames_u8, plan)
         N, step = frames_u8.shape[0], self.max_frames_per_call
         if N <= step:
             gray, rgb3 = self._pre(frames_u8, bordered3=True)
@@ -125,6 +129,38 @@ class HotPath(object):
                 g, rgb3 = self._pre(frames_u8[c0:c1], bordered3=True)
                 gray[c0:c1] = g
                 self.resnet.get_vec(rgb3, out=feats[c0:c1])
+        return self._rows(gray, feats, plan)
+
+    def _forward_u8_host(self, frames, plan):
+        """frames_u8 on the HOST (pinned: stream.pin): uploaded `upload_chunk_frames` at a time on a copy stream, chunk c+1 in
+        flight while preprocessing + ResNet50 run on chunk c (stream.FrameStream) -- the build's counterpart of the reference's
+        per-batch DataLoader feed (api/resnet50_extractor.py:53-72, api/tester.py:65-73).  Same rows as the device-resident
+        call, bit for bit (frames are independent through preprocessing and the trunk)."""
+        from .stream import FrameStream
+        if frames.dtype != torch.uint8 or tuple(frames.shape[1:]) != (112, 112, 3):
+            raise ValueError("frames must be uint8 [N,112,112,3]")
+        N = frames.shape[0]
+        chunk = min(self.max_frames_per_call, self.upload_chunk_frames)
+        key = torch.cuda.current_stream().cuda_stream
+        fs = self._feeders.get(key)
+        if fs is None or fs.slots[0].shape[0] != chunk:
+            if len(self._feeders) > 8:
+                self._feeders.clear()
+            fs = self._feeders[key] = FrameStream(self.device, chunk)
+        gray = torch.empty((N, self._pre.phase_size, self._pre.phase_size), dtype=torch.float32, device=self.device)
+        feats = torch.empty((N, 2048), dtype=torch.float32, device=self.device)
+        starts = list(range(0, N, chunk))
+        fs.upload(0, [frames[0:min(N, chunk)]])
+        for i, c0 in enumerate(starts):
+            c1, slot = min(N, c0 + chunk), i % 2
+            if i + 1 < len(starts):
+                n0 = starts[i + 1]
+                fs.upload((i + 1) % 2, [frames[n0:min(N, n0 + chunk)]])
+            dev = fs.acquire(slot)
+            g, rgb3 = self._pre(dev, bordered3=True)
+            gray[c0:c1] = g
+            self.resnet.get_vec(rgb3, out=feats[c0:c1])
+            fs.release(slot)
         return self._rows(gray, feats, plan)
 
     def _check(self, plan, n_frames, independent_clips):

@@ -108,12 +108,15 @@ class Tester(object):
         return {video_name: pd.DataFrame(data=res[0], columns=self.label_name)}
 
     def test_frames(self, clips_u8, names=None):
-        """clips_u8: list of uint8 arrays [n_i,112,112,3] (aligned faces).  -> {name: DataFrame}."""
+        """clips_u8: list of uint8 arrays [n_i,112,112,3] (aligned faces).  -> {name: DataFrame}.
+        The frames stay on the host (pinned) and are streamed to the GPU chunk by chunk under the compute of the previous
+        chunk (HotPath._forward_u8_host): a long video never sits on the device as a whole."""
         import pandas as pd
-        frames = torch.from_numpy(np.ascontiguousarray(np.concatenate(clips_u8))).to(self.device)
+        from .stream import pin
+        frames = pin(np.concatenate(clips_u8) if len(clips_u8) != 1 else np.asarray(clips_u8[0]))
         plan = self.hot.plan([len(c) for c in clips_u8])
         with torch.no_grad():
-            out = self.hot.forward_u8(frames, plan)  # PIL-exact preprocessing on the GPU
+            out = self.hot.forward_u8(frames, plan)  # upload + PIL-exact preprocessing on the GPU
         res = self.hot.assemble(out, plan, self.label_name)
         names = names or ["clip%d" % i for i in range(len(clips_u8))]
         return {names[i]: pd.DataFrame(data=res[i], columns=self.label_name) for i in range(len(clips_u8))}

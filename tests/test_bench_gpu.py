@@ -42,6 +42,35 @@ def test_one_rank_process_group_over_rccl():
     assert d["n_gpus"] == 1 and d["config"]["work_queue"]["broadcast"] == "nccl" and d["value"] > 0
 
 
+def test_forced_process_group_agrees_with_the_plain_single_rank_run():
+    """SCALE's N = 1 point must equal BENCH: the same step with and without the (one-rank, RCCL) process group -- identical
+    rows, throughput within run-to-run noise -- and the forced run carries the per-rank diagnostic row."""
+    common = ("--gpus", 1, "--steps", 6, "--warmup", 2, "--clips", 8, "--no-cpu-baseline", "--no-extra")
+    a = _bench(*common)
+    b = _bench("--force-dist", *common)
+    assert "per_rank" not in a and len(b["per_rank"]) == 1 and b["per_rank"][0]["frames"] == 6 * 8 * 64
+    assert b["per_rank"][0]["ms_per_step_local"] <= b["per_rank"][0]["ms_per_step"] * 1.001
+    # 1 % is the acceptance bound at the full 32-clip step; these 8-clip steps are 4x shorter and fresh-process noise is
+    # correspondingly larger, so the assert allows 3 % and prints the ratio
+    ratio = b["value"] / a["value"]
+    print("force-dist / plain throughput: %.4f" % ratio)
+    assert 0.97 < ratio < 1.03, ratio
+
+
+def test_streamed_input_gives_the_same_rows_and_rate(tmp_path):
+    """--stream-input: every step's uint8 frames come from pinned host memory through the copy stream.  Bit-identical rows;
+    the default line's extra.streamed reports it beside the resident form."""
+    common = ("--steps", 3, "--warmup", 1, "--clips", 6, "--total-clips", 12, "--distinct-clips", 12, "--no-cpu-baseline")
+    a = _bench("--no-extra", "--dump-out", tmp_path / "res.npy", *common)
+    b = _bench("--stream-input", "--extra-steps", 2, "--dump-out", tmp_path / "str.npy", *common)
+    assert "streamed" in b["config"]["input"] and "streamed" not in a["config"]["input"]
+    np.testing.assert_array_equal(np.load(tmp_path / "res.npy"), np.load(tmp_path / "str.npy"))
+    st = b["extra"]["streamed"]
+    assert st["pcie_bytes_per_step"] == 6 * 64 * 112 * 112 * 3 and st["value"] > 0 and st["resident_value"] > 0
+    print("streamed / resident: %.4f (%.2f GB/s over PCIe)" % (st["streamed_over_resident"], st["pcie_GB_per_s"]))
+    assert st["streamed_over_resident"] > 0.9
+
+
 def test_default_line_has_the_contract_fields():
     d = _bench("--steps", 2, "--warmup", 1, "--clips", 4, "--cpu-clips", 1, "--extra-steps", 1)
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
@@ -54,4 +83,5 @@ def test_default_line_has_the_contract_fields():
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["cpu_model"] and cb["deduplicated"]["value"] > 0
     ex = d["extra"]
     assert ex["direct_form"]["value"] > 0 and ex["multi_snippet"]["gru_seq_len"] == 5 and ex["multi_snippet"]["value"] > 0
+    assert ex["streamed"]["value"] > 0 and ex["streamed"]["pcie_GB_per_s"] > 0
     assert d["parity_vs_cpu_sample"]["max_abs_err_valence_arousal"] < 1e-4

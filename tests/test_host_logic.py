@@ -142,6 +142,22 @@ def test_bench_gpus_flag_spawns_that_many_ranks(tmp_path):
     assert list(rows[::64, 0]) == [2, 4, 3, 5] and (rows[:64, 1] == np.arange(64)).all()
 
 
+def test_bench_eight_ranks_report_one_row_per_rank():
+    """The driver's scaling run ends at 8 ranks: same launcher path with 8 stub ranks (gloo), and the JSON line carries one
+    diagnostic row per rank (its own step time, the step time incl. the wait for peers, its frames, the queue broadcast time)
+    so that a poor 8-GPU number can be attributed to a rank, to the gather or to the communicator set-up."""
+    r, d = _run_bench("--gpus", 8, "--stub-compute", "--steps", 2, "--warmup", 1, "--clips", 2, "--total-clips", 64,
+                      "--distinct-clips", 64, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert d["n_gpus"] == 8 and d["config"]["work_queue"]["clips_this_rank"] == 8
+    pr = d["per_rank"]
+    assert [x["rank"] for x in pr] == list(range(8))
+    assert all(x["frames"] == 2 * 2 * 64 for x in pr)
+    assert all(x["ms_per_step"] >= x["ms_per_step_local"] >= 0 and x["queue_broadcast_ms"] >= 0 for x in pr)
+    assert abs(max(x["ms_per_step"] for x in pr) - d["ms_per_step"]) < 1e-6          # the headline time IS the slowest rank's
+    assert d["value"] == pytest.approx(8 * 2 * 2 * 64 / (d["ms_per_step"] * 2 * 1e-3), rel=1e-6)
+
+
 def test_bench_gpus_flag_must_match_launcher_world_size():
     r, d = _run_bench("--gpus", 4, "--stub-compute", env=dict(os.environ, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0"))
     assert r.returncode != 0 and d is None and "does not match WORLD_SIZE" in r.stderr

@@ -129,6 +129,41 @@ def test_conv_engine_is_deterministic_under_load(pkg, dev, case):
         assert torch.equal(run(x[lo:lo + nb].contiguous()), first[lo:lo + nb])
 
 
+@pytest.mark.parametrize("tile", [4, 1])
+def test_conv_engine_at_the_32bit_offset_limit(pkg, dev, tile):
+    """The engine addresses a block's rows with 32-bit byte offsets from the block's first image (conv_mfma.hip: the A
+    descriptor is rebased per block); conv_forward refuses shapes where `span` images exceed 2^31 - 4096 bytes.  Just below
+    the limit (two images of 2048 x 2047 x 64 floats = 1.07 GB each, span = 2 -> 2 146 435 072 B) the 256-row tile (force_tile 4,
+    the largest) and the 128x128 tile must still be exact -- first rows, rows straddling the image boundary, last rows and a
+    random sample against float64 -- and one more pixel column must be refused, not computed wrongly."""
+    from mimamo_net_amd import _lib
+    H, W, Ci, Co = 2048, 2047, 64, 64
+    assert 2 * H * W * Ci * 4 < 0x7FFFF000 <= 2 * H * (W + 1) * Ci * 4
+    g = torch.Generator(device="cpu").manual_seed(7)
+    w = (torch.rand(Co, Ci, generator=g) - 0.5) / 8
+    wd = w.to(dev)
+    x = torch.empty((2, H, W, Ci), device=dev).uniform_(-1, 1, generator=torch.Generator(device=dev).manual_seed(11))
+    out = torch.empty((2, H, W, Co), device=dev)
+    rc = _lib.lib().mm_conv2d_nhwc(_lib.ptr(x), _lib.ptr(wd), None, None, None, None, _lib.ptr(out), 2, H, W, Ci, Ci, 0, Co, Co, 0, Co,
+                                   1, 1, 1, 0, 0, tile, 0, _lib.current_stream())
+    assert rc == 0
+    M = 2 * H * W
+    rows = torch.cat([torch.arange(0, 600), torch.arange(H * W - 600, H * W + 600), torch.arange(M - 600, M),
+                      torch.randint(0, M, (4000,), generator=g)]).to(dev)
+    xs = x.view(M, Ci).index_select(0, rows).cpu().double()
+    got = out.view(M, Co).index_select(0, rows).cpu().double()
+    err = (got - xs @ w.double().t()).abs().max().item()
+    assert err < 2e-6, err
+    del x, out
+    x1 = torch.zeros((2, H, W + 1, Ci), device=dev)
+    o1 = torch.zeros((2, H, W + 1, Co), device=dev)
+    rc = _lib.lib().mm_conv2d_nhwc(_lib.ptr(x1), _lib.ptr(wd), None, None, None, None, _lib.ptr(o1), 2, H, W + 1, Ci, Ci, 0, Co, Co, 0,
+                                   Co, 1, 1, 1, 0, 0, tile, 0, _lib.current_stream())
+    assert rc == _lib.MM_ERR_INVALID_ARG
+    torch.cuda.synchronize()
+    assert float(o1.abs().max()) == 0.0      # refused before anything was launched
+
+
 def _head_inputs(bs, t, seed):
     p0 = weights.det_uniform("head.p0", (bs, t, 24, 48, 48), -1.5, 1.5, seed)
     p1 = weights.det_uniform("head.p1", (bs, t, 24, 24, 24), -1.5, 1.5, seed)

@@ -250,3 +250,27 @@ def test_plan_and_window_ids_are_validated(tester):
     ids = torch.from_numpy(sampler.window_ids(0, 64, 64)).to(dev)
     with pytest.raises(ValueError, match="window_ids must index"):
         tester.phase_difference_extractor.phase_diff_frames(torch.rand(32, 48, 48, device=dev), ids)
+
+
+def test_host_resident_frames_stream_in_chunks_with_identical_rows(tester):
+    """HotPath.forward_u8 on a pinned HOST tensor: uploaded chunk by chunk on the copy stream under the previous chunk's
+    compute (stream.FrameStream) -- bit-identical to the device-resident call, for a chunk size that does not divide the
+    video and for one larger than it."""
+    from mimamo_net_amd.stream import pin
+    clips = [synthetic.make_clip_u8(70, 150), synthetic.make_clip_u8(71, 64)]
+    host = pin(np.concatenate(clips))
+    assert host.is_pinned() and not host.is_cuda
+    plan = tester.hot.plan([150, 64])
+    keep = tester.hot.upload_chunk_frames
+    try:
+        with torch.no_grad():
+            want = tester.hot.forward_u8(host.to(tester.device), plan)
+            for chunk in (64, 100, 4096):
+                tester.hot.upload_chunk_frames = chunk
+                got = tester.hot.forward_u8(host, plan)
+                assert torch.equal(got, want), chunk
+            # pageable source: still correct (the copy is then synchronous with the host)
+            got = tester.hot.forward_u8(torch.from_numpy(np.concatenate(clips)), plan)
+            assert torch.equal(got, want)
+    finally:
+        tester.hot.upload_chunk_frames = keep
