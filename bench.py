@@ -30,6 +30,11 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# One hardware queue per HIP stream this process uses: the three lane streams, torch's default stream, the copy stream of a
+# streamed input and RCCL's own stream.  The runtime's default of 4 queues makes two of them share one as soon as the RCCL
+# process group exists, which serialises two lanes: measured 111.6 vs 107.5 ms per step with / without a (one-rank) RCCL group,
+# 108.2 vs 107.9 with 8 queues (tools/ab_force_dist.sh).  Read by the HIP runtime when it initialises: set before torch loads it.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
@@ -310,6 +315,8 @@ def parse_args(argv=None):
     ap.add_argument("--force-dist", action="store_true",
                     help="testing only: create the process group (RCCL) even with one rank, to exercise the broadcast / "
                          "all-gather path on a single-GPU box")
+    ap.add_argument("--no-step-gather", action="store_true",
+                    help="diagnosis only: keep the process group but skip the per-step all-gather of the result rows")
     ap.add_argument("--stub-compute", action="store_true", help="testing only: no GPU work (launcher / work-queue plumbing)")
     ap.add_argument("--dump-out", default="", help="testing only: rank 0 saves the gathered rows of the last step (.npy)")
     ap.add_argument("--no-winograd", action="store_true", help="run every 3x3 layer in the direct implicit-GEMM form")
@@ -411,7 +418,7 @@ def run_rank(args):
             out = comp.step_streamed(content(ids), content(nxt) if nxt else None)
         else:
             out = comp.step(content(ids))
-        if world > 1 or args.force_dist:
+        if (world > 1 or args.force_dist) and not args.no_step_gather:
             drain()
             rows = args.clips * FRAMES_PER_CLIP
             if out.shape[0] != rows:      # ragged tail of the queue (--whole-job): pad to the step shape, NaN = no clip

@@ -108,18 +108,25 @@ int mm_phase_extract(mm_pyramid_t* h, const float* coeff, const int32_t* ids,
 int mm_phase_extract_generic(const float* coeff, int64_t planes, int P, int R, int C, float* out, float* denoised,
                              void* stream);
 
-/* Fused, de-duplicated driver for one batch of frames (the build's fast path): pyramid once
- * per unique frame, then J windows gathered through window ids (snippet_sampler.py:144-152).
- * frames [n,size,size]; ids int32 [J*13] in [0,n), each window a run of CONSECUTIVE frames with repeats only at its ends
- * (ids[i+1] - ids[i] in {0, 1}: what the sampler's clamped windows are) -- the per-frame planes carry their unwrap
- * decision relative to the preceding frame of the stack (csrc/phase_frames.hip); other index patterns go through
- * mm_pyramid_build_batch + mm_phase_extract.  Outputs as in mm_phase_extract for W=size (out0) and W=size/2 (out1).
- * workspace: mm_phase_workspace_bytes(n) bytes of HBM. */
+/* Fused, de-duplicated driver for one batch of frames (the build's fast path): ONE kernel per unique frame (pyramid,
+ * atan2 / magnitude, the frame-only blurs; csrc/pyramid_frames.hip), then J windows gathered through window ids
+ * (snippet_sampler.py:144-152; csrc/phase_frames.hip).
+ * frames [n,size,size]; ids int32 [J*13] in [0,n): ANY frame pattern -- the unwrap decisions are taken between the
+ * consecutive frames of each window from the frames' phase planes, as the reference takes them (an id outside [0,n) is
+ * clamped into range, never dereferenced).  Outputs as in mm_phase_extract for W=size (out0) and W=size/2 (out1).
+ * workspace: mm_phase_workspace_bytes(n) bytes of HBM: the per-frame planes, level 1 then level 2, each
+ * [n][nbands]{magnitude, B = blur(mag phase)/blur(mag), R = 1/blur(mag), phase}[W][W] f32. */
 int64_t mm_phase_workspace_bytes(mm_pyramid_t* h, int64_t n);
 int mm_phase_diff_frames(mm_pyramid_t* h, const float* frames, int64_t n, const int32_t* ids, int64_t J,
                          float* out0, int out0_nhwc, int out0_cstride, int out0_coffset,
                          float* out1, int out1_nhwc, int out1_cstride, int out1_coffset,
                          void* workspace, int64_t workspace_bytes, void* stream);
+
+/* The window half of mm_phase_diff_frames on its own: J windows from per-frame planes of ONE level that the caller keeps
+ * (the layout mm_phase_diff_frames leaves in its workspace: [n][nbands]{mag, B, R, phase}[W][W], W = size or size/2), e.g.
+ * to re-window cached frames with other ids.  out as in mm_phase_extract. */
+int mm_phase_diff_planes(mm_pyramid_t* h, const float* planes, int64_t n, const int32_t* ids, int64_t J, int W,
+                         float* out, int out_nhwc, int out_cstride, int out_coffset, void* stream);
 
 /* ---------------------------------------------------------------------------------------
  * General complex steerable pyramid -- replaces `SCFpyr_PyTorch(height, nbands, scale_factor,

@@ -31,6 +31,7 @@ SIGNATURES = {
     "mm_phase_extract_generic": (_i, [_vp, _i64, _i, _i, _i, _vp, _vp, _vp]),
     "mm_phase_workspace_bytes": (_i64, [_vp, _i64]),
     "mm_phase_diff_frames": (_i, [_vp, _vp, _i64, _vp, _i64, _vp, _i, _i, _i, _vp, _i, _i, _i, _vp, _i64, _vp]),
+    "mm_phase_diff_planes": (_i, [_vp, _vp, _i64, _vp, _i64, _i, _vp, _i, _i, _i, _vp]),
     "mm_scfpyr_create": (_i, [_c.POINTER(_vp), _i, _i, _i, _i]),
     "mm_scfpyr_destroy": (_i, [_vp]),
     "mm_scfpyr_host_table": (_i, [_i, _i, _i, _i, _i, _c.POINTER(_c.c_double), _c.POINTER(_i), _c.POINTER(_i)]),

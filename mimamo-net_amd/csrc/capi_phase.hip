@@ -14,8 +14,8 @@ int launch_phase_window(const float* coeff, const int32_t* ids, int64_t img_stri
                         int W, float* out, int out_nhwc, int out_cstride, int out_coffset, int polar, hipStream_t stream);
 
 int64_t phase_frames_floats(int W, int64_t n);
-int launch_phase_frames(const float* polar, int64_t img_stride, int64_t band_stride, float* fr, int64_t n, int W, hipStream_t s);
-int launch_phase_window2(const float* fr, const int32_t* ids, int64_t J, int W, float* out, int out_nhwc, int out_cstride,
+int launch_pyramid_frames(const mm_pyramid* h, const float* frames, int64_t n, float* f1, float* f2, hipStream_t stream);
+int launch_phase_window2(const float* fr, const int32_t* ids, int64_t n, int64_t J, int W, float* out, int out_nhwc, int out_cstride,
                          int out_coffset, hipStream_t s);
 
 static int check_config(int size, int height, int nbands, int scale_factor) {
@@ -132,10 +132,9 @@ int mm_phase_extract(mm_pyramid_t* h, const float* coeff, const int32_t* ids, in
 
 int64_t mm_phase_workspace_bytes(mm_pyramid_t* h, int64_t n) {
     if (!h || n < 0) return MM_ERR_INVALID_ARG;
-    const int64_t S = h->cfg.size, nb = h->cfg.nbands;
-    // polar coefficient planes of both levels + the per-frame planes of phase_frames.hip (mag, B, R, wrap flags)
-    return (n * nb * (S * S * 2 + (S / 2) * (S / 2) * 2) + mm::phase_frames_floats((int)S, n) + mm::phase_frames_floats((int)S / 2, n)) *
-           (int64_t)sizeof(float);
+    const int64_t S = h->cfg.size;
+    // the per-frame planes of both levels (mag, B, R, phase per band: pyramid_frames.hip) -- 92 KB per frame
+    return (mm::phase_frames_floats((int)S, n) + mm::phase_frames_floats((int)S / 2, n)) * (int64_t)sizeof(float);
 }
 
 int mm_phase_diff_frames(mm_pyramid_t* h, const float* frames, int64_t n, const int32_t* ids, int64_t J, float* out0,
@@ -144,26 +143,29 @@ int mm_phase_diff_frames(mm_pyramid_t* h, const float* frames, int64_t n, const 
     if (!h || n <= 0 || J < 0 || !frames || !ids || !out0 || !out1 || !workspace) return MM_ERR_INVALID_ARG;
     if (workspace_bytes < mm_phase_workspace_bytes(h, n)) return MM_ERR_WORKSPACE;
     MM_CHECK_DEVICE(h);
-    const int64_t S = h->cfg.size, nb = h->cfg.nbands;
-    const int64_t plane1 = S * S * 2, plane2 = (S / 2) * (S / 2) * 2;
-    float* c1 = (float*)workspace;           // [n][nb][S][S][2]      (phase, magnitude)
-    float* c2 = c1 + n * nb * plane1;        // [n][nb][S/2][S/2][2]
-    float* f1 = c2 + n * nb * plane2;        // frame planes, level 1
+    const int64_t S = h->cfg.size;
+    float* f1 = (float*)workspace;           // frame planes, level 1: [n][band]{mag, B, R, phase}[S][S]
     float* f2 = f1 + mm::phase_frames_floats((int)S, n);
     hipStream_t s = (hipStream_t)stream;
     if (out0_nhwc && (out0_cstride < out0_coffset + 24 || out0_coffset < 0 || (out0_cstride | out0_coffset) & 3)) return MM_ERR_INVALID_ARG;
     if (out1_nhwc && (out1_cstride < out1_coffset + 24 || out1_coffset < 0 || (out1_cstride | out1_coffset) & 3)) return MM_ERR_INVALID_ARG;
-    // pyramid once per unique frame, store epilogue writes (phase, magnitude): atan2 / sqrt once per frame
-    int rc = mm::launch_pyramid(h, frames, n, n, c1, 0, nb * plane1, plane1, c2, 0, nb * plane2, plane2, 1, s);
+    // once per unique frame: pyramid, atan2 / magnitude, the frame-only blurs (B, R) -- one kernel; then one blur per (window, frame)
+    int rc = mm::launch_pyramid_frames(h, frames, n, f1, f2, s);
     if (rc != MM_OK) return rc;
-    // per unique frame: blurred ratio B, reciprocal blurred magnitude R, wrap flags; then one blur per (window, frame)
     mm::prof_before(2, (double)J * 2 * 12 * (S * S + (S / 2) * (S / 2)) * 4, s);   // algorithmic write: 24 + 24 difference planes
-    rc = mm::launch_phase_frames(c1, nb * plane1, plane1, f1, n, (int)S, s);
-    if (rc == MM_OK) rc = mm::launch_phase_frames(c2, nb * plane2, plane2, f2, n, (int)S / 2, s);
-    if (rc == MM_OK) rc = mm::launch_phase_window2(f1, ids, J, (int)S, out0, out0_nhwc, out0_cstride, out0_coffset, s);
-    if (rc == MM_OK) rc = mm::launch_phase_window2(f2, ids, J, (int)S / 2, out1, out1_nhwc, out1_cstride, out1_coffset, s);
+    rc = mm::launch_phase_window2(f1, ids, n, J, (int)S, out0, out0_nhwc, out0_cstride, out0_coffset, s);
+    if (rc == MM_OK) rc = mm::launch_phase_window2(f2, ids, n, J, (int)S / 2, out1, out1_nhwc, out1_cstride, out1_coffset, s);
     mm::prof_after(2, s);
     return rc;
+}
+
+int mm_phase_diff_planes(mm_pyramid_t* h, const float* planes, int64_t n, const int32_t* ids, int64_t J, int W, float* out,
+                         int out_nhwc, int out_cstride, int out_coffset, void* stream) {
+    if (!h || n <= 0 || J < 0 || !planes || (J > 0 && (!ids || !out))) return MM_ERR_INVALID_ARG;
+    MM_CHECK_DEVICE(h);
+    if (W != h->cfg.size && W != h->cfg.size / 2) return MM_ERR_UNSUPPORTED;
+    if (out_nhwc && (out_cstride < out_coffset + 24 || out_coffset < 0 || (out_cstride | out_coffset) & 3)) return MM_ERR_INVALID_ARG;
+    return mm::launch_phase_window2(planes, ids, n, J, W, out, out_nhwc, out_cstride, out_coffset, (hipStream_t)stream);
 }
 
 }  // extern "C"

@@ -8,136 +8,26 @@
 // between the up-to-13 windows that contain a frame.  But the blur is linear and acc is a multiple of 2 pi:
 //   blur(mag (phase + acc)) / blur(mag) = blur(mag phase) / blur(mag)  +  blur(mag acc) / blur(mag)
 //                                       = B_i                          +  blur(mag_i * acc_i) * R_i
-// with B_i, R_i = 1 / blur(mag_i) per UNIQUE frame (phase_frame_kernel, once) and ONE blur per (window, frame) left
-// (phase_window2_kernel); where no pixel of a window has wrapped yet (always true for its first frame, and for whole windows
-// of slowly moving faces) that blur is skipped.  torch_unwrap only corrects positive jumps (fmod keeps the dividend's sign,
-// quirk Q2): corr_t = -2 pi where dd_t = phase_t - phase_{t-1} >= pi (decided on the same fp32 expression as the reference,
-// (dd + pi) >= 2 pi), else 0 up to a rounding residue of (dd + pi) - pi - dd <= 2.4e-7 that the reference accumulates and this
-// form drops -- far inside the phase tolerance (tests: 1e-3 max / 3e-4 p99.99).  So a frame carries one wrap FLAG per pixel
-// (w_t, vs its predecessor in the stack) and a window sums the flags of its frames: acc = -2 pi * k.  Window ids are clamped
-// inside a video (snippet_sampler.py:144-152), so consecutive ids are equal (repeated edge frame: dd = 0, no wrap) or
-// consecutive frames.
+// with B_i, R_i = 1 / blur(mag_i) per UNIQUE frame (pyramid_frame_kernel, pyramid_frames.hip: the pyramid's epilogue) and ONE blur
+// per (window, frame) left (phase_window2_kernel, here); where no pixel of a window has wrapped yet (always true for its first
+// frame, and for whole windows of slowly moving faces) that blur is skipped.  torch_unwrap only corrects positive jumps (fmod keeps
+// the dividend's sign, quirk Q2): corr_t = -2 pi where dd_t = phase_t - phase_{t-1} exceeds pi -- decided on the reference's own
+// fp32 expression, (dd + pi) > 2 pi: at exact equality fmod gives 0, ddmod = -pi is reset to +pi (dd > 0) and the correction is
+// ~0, not -2 pi -- else 0 up to a rounding residue of (dd + pi) - pi - dd <= 2.4e-7 that the reference accumulates and this form
+// drops (far inside the phase tolerance; tests: 1e-3 max / 3e-4 p99.99 and a tight regression bound).  A window counts, per pixel,
+// the corrected steps between ITS consecutive frames from the frames' phase planes: acc = -2 pi * k.  Any id pattern is therefore
+// handled like the reference handles it (a repeated edge frame of a clamped window, snippet_sampler.py:144-152, has dd = 0).
 #include "mm_common.h"
 #include "phase_math.h"
+#include "phase_blur.h"
 
 namespace mm {
 
-namespace {
-constexpr int P = 13, TAP = 11, R = 5, PX = 4, PADX = 8;
-__device__ constexpr float c_g[TAP] = {0.043936934322118759f, 0.1353352814912796f, 0.32465246319770813f,
-                                       0.60653066635131836f,  0.88249689340591431f, 1.0f,
-                                       0.88249689340591431f,  0.60653066635131836f, 0.32465246319770813f,
-                                       0.1353352814912796f,   0.043936934322118759f};
-
-template <int W>
-struct Cfg {
-    static constexpr int STRIPS = W / PX;
-    static constexpr int ACTIVE = STRIPS * W;                 // 576 (W = 48) / 144 (W = 24)
-    static constexpr int NTHREADS = (ACTIVE + 63) / 64 * 64;
-    static constexpr int IN_PLANE = W * W + 2 * PADX;         // un-padded rows (lane-linear, conflict free) + slack for clamped halo reads
-    static constexpr int TMP_PLANE = (W + 2 * R) * W;         // zero rows above / below
-    static constexpr int PLANE = W * W;
-    // per (frame, band) planes in the workspace, floats: mag, B, R, then W*W wrap-flag bytes
-    static constexpr int FRAME_FLOATS = 3 * PLANE + PLANE / 4;
-};
-
-// separable 11-tap pass over rows: in[y][x0-8 .. x0+12) -> h[4]; slots outside the row are zero (Q5 zero padding)
-template <int W>
-__device__ __forceinline__ void row_pass(const float* in, int y, int x0, float (&h)[PX]) {
-    float v[PX + 2 * PADX];
-#pragma unroll
-    for (int q = 0; q < (PX + 2 * PADX) / 4; ++q) {
-        const int xs = x0 - PADX + 4 * q;
-        const bool in_row = xs >= 0 && xs < W;
-        float4 a = *reinterpret_cast<const float4*>(in + y * W + (in_row ? xs : x0));
-        if (!in_row) a = float4{0.f, 0.f, 0.f, 0.f};
-        v[4 * q] = a.x; v[4 * q + 1] = a.y; v[4 * q + 2] = a.z; v[4 * q + 3] = a.w;
-    }
-#pragma unroll
-    for (int p = 0; p < PX; ++p) {
-        float s = 0.f;
-#pragma unroll
-        for (int t = 0; t < TAP; ++t) s = fmaf(c_g[t], v[PADX - R + p + t], s);
-        h[p] = s;
-    }
-}
-
-template <int W>
-__device__ __forceinline__ void col_pass(const float* tmp, int y, int x0, float (&s)[PX]) {
-    s[0] = s[1] = s[2] = s[3] = 0.f;
-#pragma unroll
-    for (int t = 0; t < TAP; ++t) {
-        const float4 a = *reinterpret_cast<const float4*>(tmp + (y + t) * W + x0);
-        const float gk = c_g[t];
-        s[0] = fmaf(gk, a.x, s[0]); s[1] = fmaf(gk, a.y, s[1]); s[2] = fmaf(gk, a.z, s[2]); s[3] = fmaf(gk, a.w, s[3]);
-    }
-}
-}  // namespace
-
-// ---- once per unique (frame, band): B = blur(mag phase) / blur(mag), R = 1 / blur(mag), mag, wrap flag vs the previous frame
-template <int W>
-__global__ void __launch_bounds__(Cfg<W>::NTHREADS)
-phase_frame_kernel(const float* __restrict__ polar, int64_t img_stride, int64_t band_stride, float* __restrict__ fr, int64_t n) {
-    using C = Cfg<W>;
-    __shared__ __attribute__((aligned(16))) float lds[2 * C::IN_PLANE + 2 * C::TMP_PLANE];
-    float* in_num = lds;
-    float* in_den = in_num + C::IN_PLANE;
-    float* tmp_num = in_den + C::IN_PLANE;
-    float* tmp_den = tmp_num + C::TMP_PLANE;
-    const int tid = threadIdx.x;
-    const int64_t f = blockIdx.x >> 1;
-    const int band = blockIdx.x & 1;
-    const bool active = tid < C::ACTIVE;
-    const int y = active ? tid / C::STRIPS : 0;
-    const int x0 = active ? (tid - y * C::STRIPS) * PX : 0;
-    for (int i = tid; i < 2 * C::IN_PLANE + 2 * C::TMP_PLANE; i += C::NTHREADS) lds[i] = 0.f;
-    __syncthreads();
-    const float PI_F = 3.14159265358979323846f, TWO_PI_F = 6.28318530717958647692f;
-    float mag[PX], ph[PX];
-    unsigned wbits = 0;
-    if (active) {
-        const float4* src = reinterpret_cast<const float4*>(polar + f * img_stride + band * band_stride + (y * W + x0) * 2);
-        const float4 a = src[0], b = src[1];
-        ph[0] = a.x; ph[1] = a.z; ph[2] = b.x; ph[3] = b.z;
-        mag[0] = a.y; mag[1] = a.w; mag[2] = b.y; mag[3] = b.w;
-        if (f > 0) {
-            const float4* prv = reinterpret_cast<const float4*>(polar + (f - 1) * img_stride + band * band_stride + (y * W + x0) * 2);
-            const float4 c = prv[0], d = prv[1];
-            const float pp[PX] = {c.x, c.z, d.x, d.z};
-#pragma unroll
-            for (int p = 0; p < PX; ++p) {
-                const float dd = ph[p] - pp[p];
-                if (dd + PI_F >= TWO_PI_F) wbits |= 1u << (8 * p);   // the jump torch_unwrap corrects by -2 pi
-            }
-        }
-        *reinterpret_cast<float4*>(in_num + y * W + x0) = float4{mag[0] * ph[0], mag[1] * ph[1], mag[2] * ph[2], mag[3] * ph[3]};
-        *reinterpret_cast<float4*>(in_den + y * W + x0) = float4{mag[0], mag[1], mag[2], mag[3]};
-    }
-    __syncthreads();
-    if (active) {
-        float hn[PX], hd[PX];
-        row_pass<W>(in_num, y, x0, hn);
-        row_pass<W>(in_den, y, x0, hd);
-        *reinterpret_cast<float4*>(tmp_num + (y + R) * W + x0) = float4{hn[0], hn[1], hn[2], hn[3]};
-        *reinterpret_cast<float4*>(tmp_den + (y + R) * W + x0) = float4{hd[0], hd[1], hd[2], hd[3]};
-    }
-    __syncthreads();
-    if (active) {
-        float sn[PX], sd[PX];
-        col_pass<W>(tmp_num, y, x0, sn);
-        col_pass<W>(tmp_den, y, x0, sd);
-        float* o = fr + (f * 2 + band) * C::FRAME_FLOATS;
-        const int px = y * W + x0;
-        *reinterpret_cast<float4*>(o + px) = float4{mag[0], mag[1], mag[2], mag[3]};
-        *reinterpret_cast<float4*>(o + C::PLANE + px) = float4{sn[0] / sd[0], sn[1] / sd[1], sn[2] / sd[2], sn[3] / sd[3]};
-        *reinterpret_cast<float4*>(o + 2 * C::PLANE + px) = float4{1.0f / sd[0], 1.0f / sd[1], 1.0f / sd[2], 1.0f / sd[3]};
-        reinterpret_cast<unsigned*>(o + 3 * C::PLANE)[px / 4] = wbits;
-    }
-}
+using namespace blur;
 
 // ---- per (window, band): 12 phase-difference planes from the frame planes.
-//   A  every frame's B plane and wrap flags are requested up front (26 independent loads per thread, one latency instead of one
-//      per barrier round); the flags are summed bytewise in one register per frame (k <= 12 per pixel), the difference planes start
+//   A  every frame's B and phase planes are requested up front (26 independent loads per thread, one latency instead of one
+//      per barrier round); the wrapped steps are counted bytewise in one register per frame (k <= 12 per pixel), the difference planes start
 //      as B_i - B_{i-1}, and the workgroup agrees on the first frame in which ANY of its pixels has wrapped (one LDS min, one barrier)
 //   B  from that frame on, F frames per barrier round: blur(mag * (-2 pi k)) * R, whose frame-to-frame change is added to the planes.
 //      Frames before it have blur(mag * 0) = 0: rounds that end before the first wrap are skipped (always the window's first frame,
@@ -150,7 +40,7 @@ phase_frame_kernel(const float* __restrict__ polar, int64_t img_stride, int64_t 
 #endif
 template <int W>
 __global__ void __launch_bounds__(Cfg<W>::NTHREADS)
-phase_window2_kernel(const float* __restrict__ fr, const int32_t* __restrict__ ids, float* __restrict__ out, int out_nhwc,
+phase_window2_kernel(const float* __restrict__ fr, const int32_t* __restrict__ ids, int n_frames, float* __restrict__ out, int out_nhwc,
                      int out_cstride, int out_coffset) {
     using C = Cfg<W>;
     constexpr int F = MM_PHASE_FPR;
@@ -180,25 +70,28 @@ phase_window2_kernel(const float* __restrict__ fr, const int32_t* __restrict__ i
     float d[P - 1][PX];
     unsigned kb[P];
     {
-        float4 bprev = {0.f, 0.f, 0.f, 0.f};
-        int prev_id = -1;
+        float4 bprev = {0.f, 0.f, 0.f, 0.f}, pprev = {0.f, 0.f, 0.f, 0.f};
         unsigned run = 0;
 #pragma unroll
         for (int i = 0; i < P; ++i) {
-            const int id = ids[j * P + i];
+            const int id = min(max(ids[j * P + i], 0), n_frames - 1);    // memory-safe whatever the table holds (the shim range-checks it)
             fo[i] = fr + ((int64_t)id * 2 + band) * C::FRAME_FLOATS;
-            float4 b4 = {0.f, 0.f, 0.f, 0.f};
+            float4 b4 = {0.f, 0.f, 0.f, 0.f}, p4 = {0.f, 0.f, 0.f, 0.f};
             if (active) {
                 b4 = *reinterpret_cast<const float4*>(fo[i] + C::PLANE + px);
-                // a new frame: its wrap flags refer to the frame before it, which is prev_id (a repeated edge frame has dd = 0)
-                if (i > 0 && id != prev_id) run += reinterpret_cast<const unsigned*>(fo[i] + 3 * C::PLANE)[px / 4];
+                p4 = *reinterpret_cast<const float4*>(fo[i] + 3 * C::PLANE + px);
             }
-            kb[i] = run;
             if (i > 0) {
+                // the steps torch_unwrap corrects by -2 pi (phase_utils.py:9-17), on its own fp32 expression
+                if ((p4.x - pprev.x) + PI_F > TWO_PI_F) run += 1u;
+                if ((p4.y - pprev.y) + PI_F > TWO_PI_F) run += 1u << 8;
+                if ((p4.z - pprev.z) + PI_F > TWO_PI_F) run += 1u << 16;
+                if ((p4.w - pprev.w) + PI_F > TWO_PI_F) run += 1u << 24;
                 d[i - 1][0] = b4.x - bprev.x; d[i - 1][1] = b4.y - bprev.y; d[i - 1][2] = b4.z - bprev.z; d[i - 1][3] = b4.w - bprev.w;
             }
+            kb[i] = run;
             bprev = b4;
-            prev_id = id;
+            pprev = p4;
         }
     }
     {
@@ -317,27 +210,15 @@ phase_window2_kernel(const float* __restrict__ fr, const int32_t* __restrict__ i
     }
 }
 
-int64_t phase_frames_floats(int W, int64_t n) { return n * 2 * (W == 48 ? Cfg<48>::FRAME_FLOATS : Cfg<24>::FRAME_FLOATS); }
-
-// polar planes [n][2][W][W][2] (phase, magnitude) -> frame planes; then windows -> out
-int launch_phase_frames(const float* polar, int64_t img_stride, int64_t band_stride, float* fr, int64_t n, int W, hipStream_t s) {
-    if (n <= 0) return MM_OK;
-    const dim3 grid((unsigned)(2 * n));
-    if (W == 48) hipLaunchKernelGGL(phase_frame_kernel<48>, grid, dim3(Cfg<48>::NTHREADS), 0, s, polar, img_stride, band_stride, fr, n);
-    else if (W == 24) hipLaunchKernelGGL(phase_frame_kernel<24>, grid, dim3(Cfg<24>::NTHREADS), 0, s, polar, img_stride, band_stride, fr, n);
-    else return MM_ERR_UNSUPPORTED;
-    MM_LAUNCH_CHECK();
-    return MM_OK;
-}
-
-int launch_phase_window2(const float* fr, const int32_t* ids, int64_t J, int W, float* out, int out_nhwc, int out_cstride,
+int launch_phase_window2(const float* fr, const int32_t* ids, int64_t n, int64_t J, int W, float* out, int out_nhwc, int out_cstride,
                          int out_coffset, hipStream_t s) {
     if (J <= 0) return MM_OK;
+    if (n <= 0 || n > 0x7fffffff || 2 * J > 0x7fffffff) return MM_ERR_INVALID_ARG;
     const dim3 grid((unsigned)(2 * J));
     if (W == 48)
-        hipLaunchKernelGGL(phase_window2_kernel<48>, grid, dim3(Cfg<48>::NTHREADS), 0, s, fr, ids, out, out_nhwc, out_cstride, out_coffset);
+        hipLaunchKernelGGL(phase_window2_kernel<48>, grid, dim3(Cfg<48>::NTHREADS), 0, s, fr, ids, (int)n, out, out_nhwc, out_cstride, out_coffset);
     else if (W == 24)
-        hipLaunchKernelGGL(phase_window2_kernel<24>, grid, dim3(Cfg<24>::NTHREADS), 0, s, fr, ids, out, out_nhwc, out_cstride, out_coffset);
+        hipLaunchKernelGGL(phase_window2_kernel<24>, grid, dim3(Cfg<24>::NTHREADS), 0, s, fr, ids, (int)n, out, out_nhwc, out_cstride, out_coffset);
     else return MM_ERR_UNSUPPORTED;
     MM_LAUNCH_CHECK();
     return MM_OK;

@@ -20,25 +20,16 @@
 // 256-thread workgroup per frame (both bands off one DCT), operands staged in LDS with bank-conflict-free strides.
 #include "mm_common.h"
 #include "phase_math.h"
+#include "pyramid_tables.h"
 
 namespace mm {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int S = 48;        // frame side
+using namespace pyr;          // S and the table offsets (pyramid_tables.h)
 constexpr int LDD = 49;      // D as A/B operand: odd stride
 constexpr int NT = 256;      // threads per workgroup (512 measured slower: 0.62 vs 0.46 ms per 2048 frames)
 constexpr int NW = NT / 64;  // waves
-
-// global table offsets (floats)
-constexpr int OFF_DCT = 0;
-constexpr int OFF_EC = OFF_DCT + S * S;
-constexpr int OFF_ES = OFF_EC + S * S;
-constexpr int OFF_M1B0 = OFF_ES + S * S;            // [96][48][2]
-constexpr int OFF_M1B1 = OFF_M1B0 + 96 * 48 * 2;    // [48][96][2]
-constexpr int OFF_M2B0 = OFF_M1B1 + 96 * 48 * 2;    // [48][24][2]
-constexpr int OFF_M2B1 = OFF_M2B0 + 48 * 24 * 2;    // [24][48][2]
-constexpr int TABLE_FLOATS = OFF_M2B1 + 48 * 24 * 2;
 
 // LDS carve (floats)
 constexpr int L_DCT = 0;                       // [48][49]

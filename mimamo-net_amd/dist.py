@@ -207,7 +207,9 @@ def spawn_ranks(argv, n_ranks, env=None, timeout=None):
     import time
     base = dict(os.environ if env is None else env)
     base.update({"WORLD_SIZE": str(n_ranks), "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(free_port()),
-                 "HSA_ENABLE_IPC_MODE_LEGACY": base.get("HSA_ENABLE_IPC_MODE_LEGACY", "0")})
+                 "HSA_ENABLE_IPC_MODE_LEGACY": base.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"),
+                 # a hardware queue per stream (lanes + default + copy + RCCL's): see bench.py
+                 "GPU_MAX_HW_QUEUES": base.get("GPU_MAX_HW_QUEUES", "8")})
     tmp = tempfile.mkdtemp(prefix="mm_ranks_")
     procs, files = [], []
     for r in range(n_ranks):

@@ -151,13 +151,15 @@ class Phase_Difference_Extractor(object):
         api/sampler/snippet_sampler.py:144-152) -> (phase_0 [J,24,W,W], phase_1 [J,24,W/2,W/2]).
 
         Builds each frame's pyramid once instead of once per window that contains it (13x less work than
-        Tester.phase_diff_output, identical results because the pyramid is per-frame -- quirk Q3).
+        Tester.phase_diff_output; quirk Q3) and blurs everything that is linear in the frame once per frame: equal to the
+        windowed evaluation up to fp32 rounding of the regrouping B + blur(mag * acc) * R (csrc/phase_frames.hip; tests:
+        <= 5e-5 against the literal kernel).
         nhwc=True writes channels-last tensors ([J,W,W,24], [J,W/2,W/2,out1_cstride] with the 24 channels
         at out1_coffset) for the head's conv engine.
-        The ids index planes of the N-frame workspace and must step by 0 or +1 inside a window (the per-frame planes
-        carry their unwrap decision relative to the preceding frame, csrc/phase_frames.hip): both are checked on the host
-        the first time a table is seen (one device->host read, cached per table); ids_checked=True skips that for tables
-        the caller built from the same frame count (HotPath.plan)."""
+        The ids index the N frames handed over; any pattern is allowed (the unwrap decisions are taken between the
+        consecutive frames of each window).  The range is checked on the host the first time a table is seen (one
+        device->host read, cached per table); ids_checked=True skips that for tables the caller built from the same
+        frame count (HotPath.plan)."""
         self._check_input(frames, 3, "frames")
         N, W, _ = frames.shape
         J = window_ids.shape[0]
@@ -165,15 +167,10 @@ class Phase_Difference_Extractor(object):
         if not ids_checked and J > 0:
             hit = self._ids_ok.get(id(window_ids))
             if not (hit is not None and hit[0]() is window_ids and hit[1] == (window_ids._version, N)):
-                step = window_ids[:, 1:] - window_ids[:, :-1]
-                chk = torch.stack([window_ids.min(), window_ids.max(), step.min(), step.max()]).tolist()   # one device->host read
+                chk = torch.stack([window_ids.min(), window_ids.max()]).tolist()   # one device->host read
                 lo, hi = int(chk[0]), int(chk[1])
                 if lo < 0 or hi >= N:
                     raise ValueError("window_ids must index the %d frames handed over (found %d..%d)" % (N, lo, hi))
-                if chk[2] < 0 or chk[3] > 1:
-                    raise ValueError("every window must be a run of consecutive frames with repeats only at its ends (clamped "
-                                     "windows, snippet_sampler.py:144-152): found index steps in %d..%d; use build_pyramid + "
-                                     "extract for other patterns" % (int(chk[2]), int(chk[3])))
                 if len(self._ids_ok) > 64:
                     self._ids_ok.clear()
                 self._ids_ok[id(window_ids)] = (weakref.ref(window_ids), (window_ids._version, N))
@@ -201,6 +198,22 @@ class Phase_Difference_Extractor(object):
                                     *args, _lib.ptr(ws), ws_bytes, _lib.current_stream())
         _lib.check(rc, "mm_phase_diff_frames")
         return p0, p1
+
+
+    def phase_diff_planes(self, planes, window_ids, out=None):
+        """The window half of phase_diff_frames on per-frame planes the caller holds: planes [N, 2, 4, W, W] =
+        {magnitude, B = blur(mag phase)/blur(mag), R = 1/blur(mag), wrapped phase} per (frame, band), W = 48 or 24
+        (what mm_phase_diff_frames leaves in its workspace); window_ids int32 [J, 13] -> [J, 24, W, W]."""
+        self._check_input(planes, 5, "planes")
+        N, nb, four, W, _ = planes.shape
+        assert nb == 2 and four == 4 and window_ids.dtype == torch.int32 and window_ids.is_cuda
+        J = window_ids.shape[0]
+        if out is None:
+            out = torch.empty((J, 24, W, W), dtype=torch.float32, device=planes.device)
+        rc = _lib.lib().mm_phase_diff_planes(self._get(48), _lib.ptr(planes.contiguous()), N, _lib.ptr(window_ids.contiguous()), J, W,
+                                             _lib.ptr(out), 0, 0, 0, _lib.current_stream())
+        _lib.check(rc, "mm_phase_diff_planes")
+        return out
 
 
 def phase_diff_output(phase_batch, steerable_pyramid):

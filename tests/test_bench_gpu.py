@@ -45,16 +45,16 @@ def test_one_rank_process_group_over_rccl():
 def test_forced_process_group_agrees_with_the_plain_single_rank_run():
     """SCALE's N = 1 point must equal BENCH: the same step with and without the (one-rank, RCCL) process group -- identical
     rows, throughput within run-to-run noise -- and the forced run carries the per-rank diagnostic row."""
-    common = ("--gpus", 1, "--steps", 6, "--warmup", 2, "--clips", 8, "--no-cpu-baseline", "--no-extra")
+    common = ("--gpus", 1, "--steps", 8, "--warmup", 3, "--no-cpu-baseline", "--no-extra")     # the full 32-clip step
     a = _bench(*common)
     b = _bench("--force-dist", *common)
-    assert "per_rank" not in a and len(b["per_rank"]) == 1 and b["per_rank"][0]["frames"] == 6 * 8 * 64
+    assert "per_rank" not in a and len(b["per_rank"]) == 1 and b["per_rank"][0]["frames"] == 8 * 32 * 64
     assert b["per_rank"][0]["ms_per_step_local"] <= b["per_rank"][0]["ms_per_step"] * 1.001
-    # 1 % is the acceptance bound at the full 32-clip step; these 8-clip steps are 4x shorter and fresh-process noise is
-    # correspondingly larger, so the assert allows 3 % and prints the ratio
+    # Round 3 found the RCCL group costing 4 % here: its stream took the hardware queue of a lane (GPU_MAX_HW_QUEUES, bench.py).
+    # Same-box repeats of one mode differ by up to ~0.5 %; the assert allows 1.5 % and prints the ratio.
     ratio = b["value"] / a["value"]
     print("force-dist / plain throughput: %.4f" % ratio)
-    assert 0.97 < ratio < 1.03, ratio
+    assert 0.985 < ratio < 1.015, ratio
 
 
 def test_streamed_input_gives_the_same_rows_and_rate(tmp_path):

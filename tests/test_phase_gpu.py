@@ -12,6 +12,10 @@ pytestmark = pytest.mark.gpu
 COEFF_ATOL = 1e-6      # band coefficients (|c| ~ 1e-2..1e-1); reference fp32-vs-fp64 differs by 1.2e-7..2.5e-7
 PHASE_ATOL = 1e-3      # phase differences, away from +-pi branch cuts
 PHASE_P9999 = 3e-4     # 99.99th percentile of |err|
+# Regression bounds: ~3x what every run of rounds 2-3 has shown (max 2.7e-5, p99.99 < 1e-5, 0 branch flips on these inputs).  The
+# reference-derived tolerances above stay the contract; these catch a kernel that silently got worse inside them.
+PHASE_TIGHT = 1e-4
+PHASE_TIGHT_P9999 = 3e-5
 
 
 @pytest.fixture(scope="module")
@@ -42,6 +46,10 @@ def _phase_err(a, b):
     res = d[~flips].max(), np.quantile(d[~flips], 0.9999), int(flips.sum())
     print("phase error: max %.2e  p99.99 %.2e  2pi branch flips %d of %d" % (res + (d.size,)))
     return res
+
+
+def _tight(mx, p9999, flips):
+    assert mx < PHASE_TIGHT and p9999 < PHASE_TIGHT_P9999 and flips == 0, ("regression bound", mx, p9999, flips)
 
 
 def test_pyramid_golden(pde, golden, dev):
@@ -80,6 +88,7 @@ def test_extract_vs_oracle_same_coefficients(pde, oracle, dev):
         mx, p9999, flips = _phase_err(got, want)
         assert got.shape == want.shape
         assert mx < PHASE_ATOL and p9999 < PHASE_P9999 and flips <= 2, (mx, p9999, flips)
+        _tight(mx, p9999, flips)
 
 
 def test_phase_diff_output_golden(pde, golden, dev):
@@ -90,6 +99,7 @@ def test_phase_diff_output_golden(pde, golden, dev):
     for got, want in ((p0, g["phase_0"]), (p1, g["phase_1"])):
         mx, p9999, flips = _phase_err(got.cpu().numpy()[0], want)
         assert mx < PHASE_ATOL and p9999 < PHASE_P9999 and flips <= 2, (mx, p9999, flips)
+        _tight(mx, p9999, flips)
     # replicated frames (clamped window) -> exactly zero differences, like the reference
     z = p0.cpu().numpy()[0, 1]
     assert np.abs(z[0:6]).max() == 0.0 and np.abs(z[12:18]).max() == 0.0
@@ -119,6 +129,58 @@ def test_dedup_fast_path_matches_drop_in(pde, oracle, dev):
     for got, want in ((a0, o0), (a1, o1)):
         mx, p9999, flips = _phase_err(got.cpu().numpy(), want)
         assert mx < PHASE_ATOL and p9999 < PHASE_P9999 and flips <= 4, (mx, p9999, flips)
+        _tight(mx, p9999, flips)
+
+
+def test_fast_path_takes_any_window_pattern(pde, dev):
+    """The fused path decides the unwrap steps between the consecutive frames OF EACH WINDOW (from the frames' phase planes),
+    so windows that skip frames, run backwards or repeat frames in the middle equal the literal per-window kernel on the
+    gathered frames -- not only the sampler's clamped runs."""
+    from mimamo_net_amd.phase_difference_extractor import phase_diff_output
+    n = 60
+    f = torch.from_numpy(synthetic.textured_gray(n, 48, seed=91)).to(dev)
+    rng = np.random.RandomState(5)
+    pats = [np.arange(13) * 2 + 3, np.arange(13)[::-1] + 20, np.arange(13) * 4, rng.randint(0, n, 13), np.repeat(np.arange(30, 37), 2)[:13],
+            np.clip(np.arange(13) - 6 + 2, 0, n - 1)]
+    ids = torch.from_numpy(np.stack(pats).astype(np.int32)).to(dev)
+    a0, a1 = pde.phase_diff_frames(f, ids)
+    b0, b1 = phase_diff_output(f[ids.long()][None], pde)
+    for fast, lit in ((a0, b0[0]), (a1, b1[0])):
+        diff = (fast - lit).abs()
+        print("any-pattern windows, fast vs literal: max |diff| %.2e" % diff.max().item())
+        assert diff.max().item() < 5e-5
+    with pytest.raises(ValueError, match="window_ids must index"):
+        pde.phase_diff_frames(f, ids + 50)
+
+
+def test_unwrap_decision_at_exactly_pi(pde, oracle, dev):
+    """torch_unwrap at dd == fp32(pi) exactly: fmod(dd + pi, 2 pi) = 0 -> ddmod = -pi -> reset to +pi because dd > 0 -> the
+    correction is pi - dd = 0, NOT -2 pi (api/utils/phase_utils.py:9-17).  The window kernel must decide `dd + pi > 2 pi`, not
+    `>=`.  Planes are handed over directly (mm_phase_diff_planes) because no coefficient has atan2 == +pi exactly."""
+    W, P = 24, 13
+    rng = np.random.RandomState(3)
+    PI32 = np.float32(np.pi)
+    phase = rng.uniform(-0.5, 0.5, (2, P, W, W)).astype(np.float32)
+    phase[:, 0] = 0.0
+    phase[0, 1, :, :12] = PI32                        # exactly +pi after 0: no correction
+    phase[0, 1, :, 12:] = PI32 + np.float32(1e-5)     # just above: corrected by -2 pi
+    phase[1, 3] = phase[1, 2] + np.float32(4.0)       # a plain wrapped step, whole plane
+    phase[1, 7, 5:9] = phase[1, 6, 5:9] - np.float32(4.0)     # negative jump: never corrected (quirk Q2)
+    mag = rng.uniform(0.5, 1.5, (2, P, W, W)).astype(np.float32)
+    k = oracle.gaussian_kernel(2, 11)
+    want_den = oracle.amplitude_blur(mag, oracle.unwrap(phase, axis=1), k)
+    want = oracle.diff(want_den, axis=1)
+    want = np.clip(want - want.mean(-1).mean(-1)[..., None, None], -5 * PI32, 5 * PI32)
+    B = oracle.amplitude_blur(mag, phase, k)
+    R = 1.0 / torch.nn.functional.conv2d(torch.from_numpy(mag), torch.from_numpy(k).float()[None, None].repeat(P, 1, 1, 1), groups=P,
+                                         padding=5).numpy()
+    planes = np.stack([mag, B, R, phase], axis=2)     # [band, frame, 4, W, W]
+    planes = np.ascontiguousarray(planes.transpose(1, 0, 2, 3, 4))   # [frame, band, 4, W, W]
+    ids = torch.arange(P, dtype=torch.int32, device=dev)[None].contiguous()
+    got = pde.phase_diff_planes(torch.from_numpy(planes).to(dev), ids).cpu().numpy()[0].reshape(2, P - 1, W, W)
+    err = np.abs(got - want)
+    print("exact-pi unwrap case: max |err| %.2e" % err.max())
+    assert err.max() < 5e-5, err.max()
 
 
 def test_full_size_properties(pde, dev):
