@@ -608,14 +608,13 @@ def extra_legs(args, comp, ids0, n_frames):
                          "what": "same step with every 3x3 layer as a direct implicit GEMM (no Winograd)"}
     # (a2) the headline step with its input streamed over PCIe instead of resident in HBM
     if not args.from_f32:
-        seq = [ids0] * (K + 1)
         with torch.no_grad():
-            comp.step_streamed(seq[0], seq[1])
+            comp.step_streamed(ids0, ids0)             # primes the pipeline: the first timed step's frames are in flight
             torch.cuda.synchronize()
             b0 = comp._fs.bytes_uploaded
             t0 = time.perf_counter()
-            for i in range(K):
-                comp.step_streamed(seq[i + 1], seq[i + 2] if i + 2 <= K else None)
+            for i in range(K):                         # steady state: every step uploads the next step's frames while it computes
+                comp.step_streamed(ids0, ids0)
             torch.cuda.synchronize()
             dts = (time.perf_counter() - t0) / K
             up = (comp._fs.bytes_uploaded - b0) / K

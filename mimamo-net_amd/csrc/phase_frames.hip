@@ -17,6 +17,7 @@
 // drops (far inside the phase tolerance; tests: 1e-3 max / 3e-4 p99.99 and a tight regression bound).  A window counts, per pixel,
 // the corrected steps between ITS consecutive frames from the frames' phase planes: acc = -2 pi * k.  Any id pattern is therefore
 // handled like the reference handles it (a repeated edge frame of a clamped window, snippet_sampler.py:144-152, has dd = 0).
+#include <cstdlib>
 #include "mm_common.h"
 #include "phase_math.h"
 #include "phase_blur.h"
@@ -35,21 +36,19 @@ using namespace blur;
 //   C  spatial means, clamp, store.  NHWC pixels take 48 of their 96 bytes from this band: the rows go through LDS so that three
 //      consecutive lanes write the 48 contiguous bytes of a pixel (a lane-per-pixel-strip store issues 64 separate 16-byte requests
 //      per instruction: 0.16 of the 0.61 ms these kernels took)
-#ifndef MM_PHASE_FPR
-#define MM_PHASE_FPR 3      // frames per barrier round
-#endif
-template <int W>
+// F = frames per barrier round (three barriers each).  A 9-wave workgroup at ~160 registers is alone on its CU, so the whole
+// 160 KB of LDS is its to use: F planes of blur input + row-pass output.
+template <int W, int F>
 __global__ void __launch_bounds__(Cfg<W>::NTHREADS)
 phase_window2_kernel(const float* __restrict__ fr, const int32_t* __restrict__ ids, int n_frames, float* __restrict__ out, int out_nhwc,
                      int out_cstride, int out_coffset) {
     using C = Cfg<W>;
-    constexpr int F = MM_PHASE_FPR;
     constexpr int RPG = W == 48 ? 16 : 12;                    // rows per store group: RPG * W * 12 floats staged at a time
     constexpr int G = W / RPG;
     constexpr int WORK = F * (C::IN_PLANE + C::TMP_PLANE);
     static_assert(RPG * W * (P - 1) <= WORK, "store staging fits the blur planes");
-    __shared__ __attribute__((aligned(16))) float lds[WORK + 64 * (P - 1)];
-    __shared__ int first_wrap;
+    extern __shared__ __attribute__((aligned(16))) float lds[];      // WORK + 64 * (P - 1) floats + first_wrap
+    int& first_wrap = *reinterpret_cast<int*>(lds + WORK + 64 * (P - 1));
     float* in_x = lds;                              // [F][IN_PLANE]
     float* tmp_x = in_x + F * C::IN_PLANE;          // [F][TMP_PLANE]
     float* red = lds + WORK;
@@ -210,18 +209,28 @@ phase_window2_kernel(const float* __restrict__ fr, const int32_t* __restrict__ i
     }
 }
 
+template <int W, int F>
+static int launch_w2(const float* fr, const int32_t* ids, int n, int64_t J, float* out, int out_nhwc, int out_cstride, int out_coffset,
+                     hipStream_t s) {
+    using C = Cfg<W>;
+    const int lds_bytes = (F * (C::IN_PLANE + C::TMP_PLANE) + 64 * (P - 1) + 4) * 4;
+    MM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(phase_window2_kernel<W, F>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               lds_bytes));
+    hipLaunchKernelGGL((phase_window2_kernel<W, F>), dim3((unsigned)(2 * J)), dim3(C::NTHREADS), lds_bytes, s, fr, ids, n, out, out_nhwc,
+                       out_cstride, out_coffset);
+    MM_LAUNCH_CHECK();
+    return MM_OK;
+}
+
 int launch_phase_window2(const float* fr, const int32_t* ids, int64_t n, int64_t J, int W, float* out, int out_nhwc, int out_cstride,
                          int out_coffset, hipStream_t s) {
     if (J <= 0) return MM_OK;
     if (n <= 0 || n > 0x7fffffff || 2 * J > 0x7fffffff) return MM_ERR_INVALID_ARG;
-    const dim3 grid((unsigned)(2 * J));
-    if (W == 48)
-        hipLaunchKernelGGL(phase_window2_kernel<48>, grid, dim3(Cfg<48>::NTHREADS), 0, s, fr, ids, (int)n, out, out_nhwc, out_cstride, out_coffset);
-    else if (W == 24)
-        hipLaunchKernelGGL(phase_window2_kernel<24>, grid, dim3(Cfg<24>::NTHREADS), 0, s, fr, ids, (int)n, out, out_nhwc, out_cstride, out_coffset);
-    else return MM_ERR_UNSUPPORTED;
-    MM_LAUNCH_CHECK();
-    return MM_OK;
+    // F = 3 frames per barrier round; 4 / 5 / 7 measured equal or slower (0.547 / 0.554 / 0.554 / 0.593 ms per 2 048 windows):
+    // the kernel is not waiting at its barriers
+    if (W == 48) return launch_w2<48, 3>(fr, ids, (int)n, J, out, out_nhwc, out_cstride, out_coffset, s);
+    if (W == 24) return launch_w2<24, 3>(fr, ids, (int)n, J, out, out_nhwc, out_cstride, out_coffset, s);
+    return MM_ERR_UNSUPPORTED;
 }
 
 }  // namespace mm
