@@ -56,6 +56,8 @@ SIGNATURES = {
     "mm_head_create": (_i, [_c.POINTER(_vp), _vp, _i64]),
     "mm_head_blob_floats_mlp": (_i64, [_i, _c.POINTER(_i)]),
     "mm_head_create_mlp": (_i, [_c.POINTER(_vp), _vp, _i64, _i, _c.POINTER(_i)]),
+    "mm_head_blob_floats_cfg": (_i64, [_i, _c.POINTER(_i), _i]),
+    "mm_head_create_cfg": (_i, [_c.POINTER(_vp), _vp, _i64, _i, _c.POINTER(_i), _i]),
     "mm_head_destroy": (_i, [_vp]),
     "mm_head_workspace_bytes": (_i64, [_vp, _i64, _i64]),
     "mm_head_forward": (_i, [_vp, _vp, _vp, _i, _vp, _i64, _i64, _vp, _vp, _i64, _vp]),

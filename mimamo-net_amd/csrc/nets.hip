@@ -285,6 +285,7 @@ struct mm_head {
     mm::Layer conv[6], fc1, fc2, transform, gru_ih[2], gru_hh[2][2], classifier;
     float* bhh[2][2];
     int winograd;   // 1 (default): PhaseNet's 128 -> 256 3x3 layer through the fused F(4x4,3x3) kernel; MM_HEAD_WINOGRAD=0: direct form
+    int pc;         // PhaseNet input channels = 2 * num_phase (api/mimamo_net.py:112): 24 for the published model
     int device;
 };
 
@@ -319,12 +320,14 @@ static bool mlp_units_ok(int n_units, const int* units) {
     return true;
 }
 
-static int64_t head_blob_floats(int n_units, const int* units) {
+static bool phase_channels_ok(int pc) { return pc >= 4 && pc <= 64 && pc % 4 == 0; }   // 16-byte channel groups; 64 + pc <= 128 (Winograd K)
+
+static int64_t head_blob_floats(int n_units, const int* units, int pc = 24) {
     int64_t n = 0;
     auto lin = [&](int o, int i) { n += (int64_t)o * i + o; };
     auto bn = [&](int c) { n += 4 * c; };
     for (int i = 1; i < n_units; ++i) { lin(units[i], units[i - 1]); bn(units[i]); }
-    const int ch[3][2] = {{24, 64}, {88, 128}, {128, 256}};
+    const int ch[3][2] = {{pc, 64}, {64 + pc, 128}, {128, 256}};
     for (auto& c : ch) { n += (int64_t)c[1] * c[0] * 9 + c[1]; bn(c[1]); n += (int64_t)c[1] * c[1] * 9 + c[1]; bn(c[1]); }
     lin(256, 256); bn(256); lin(256, 256); bn(256); lin(1, 256); bn(1);
     lin(256, 512); bn(256);
@@ -553,16 +556,29 @@ int mm_head_create(mm_head_t** out, const float* blob, int64_t n_floats) {
 }
 
 int mm_head_create_mlp(mm_head_t** out, const float* blob, int64_t n_floats, int n_units, const int* units) {
+    return mm_head_create_cfg(out, blob, n_floats, n_units, units, 12);
+}
+
+int64_t mm_head_blob_floats_cfg(int n_units, const int* units, int num_phase) {
+    return mm::mlp_units_ok(n_units, units) && mm::phase_channels_ok(2 * num_phase) ? mm::head_blob_floats(n_units, units, 2 * num_phase)
+                                                                                      : (int64_t)MM_ERR_INVALID_ARG;
+}
+
+int mm_head_create_cfg(mm_head_t** out, const float* blob, int64_t n_floats, int n_units, const int* units, int num_phase) {
     using namespace mm;
     if (!out) return MM_ERR_INVALID_ARG;
     *out = nullptr;
+    const int pc = 2 * num_phase;
     if (!mlp_units_ok(n_units, units)) return MM_ERR_INVALID_ARG;
-    if (!blob || n_floats != head_blob_floats(n_units, units)) return MM_ERR_INVALID_ARG;
+    if (num_phase < 1) return MM_ERR_INVALID_ARG;
+    if (!phase_channels_ok(pc)) return MM_ERR_UNSUPPORTED;      // odd num_phase (channel groups of 4) or more than 32 differences
+    if (!blob || n_floats != head_blob_floats(n_units, units, pc)) return MM_ERR_INVALID_ARG;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return MM_ERR_NO_DEVICE;
     mm_head* h = new (std::nothrow) mm_head();
     if (!h) return MM_ERR_INVALID_ARG;
     h->device = current_device_or(0);
+    h->pc = pc;
     const float eps = 1e-5f;
     const float* p = blob;
     int rc = MM_OK;
@@ -596,7 +612,7 @@ int mm_head_create_mlp(mm_head_t** out, const float* blob, int64_t n_floats, int
         lin_bn_relu(h->mlp[i - 1], units[i], units[i - 1]);
         if (units[i] > h->mlp_max) h->mlp_max = units[i];
     }
-    const int ch[3][2] = {{24, 64}, {88, 128}, {128, 256}};
+    const int ch[3][2] = {{pc, 64}, {64 + pc, 128}, {128, 256}};
     for (int i = 0; i < 3; ++i) {
         conv_bn_relu(h->conv[2 * i], ch[i][1], ch[i][0], 1);
         conv_bn_relu(h->conv[2 * i + 1], ch[i][1], ch[i][1], 2);
@@ -644,9 +660,9 @@ namespace {
 struct HeadWs {
     int64_t p0n, a0, cat, a1, a2, a3, a4, pool, fc1, m1, feat, f, gi, gh, l0, l1, wv;
 };
-HeadWs head_sizes(int64_t N, int64_t T, int64_t mlp_max, bool wino) {
+HeadWs head_sizes(int64_t N, int64_t T, int64_t mlp_max, bool wino, int pc) {
     HeadWs s;
-    s.p0n = N * 48 * 48 * 24; s.a0 = N * 48 * 48 * 64; s.cat = N * 24 * 24 * 88; s.a1 = N * 24 * 24 * 128;
+    s.p0n = N * 48 * 48 * pc; s.a0 = N * 48 * 48 * 64; s.cat = N * 24 * 24 * (64 + pc); s.a1 = N * 24 * 24 * 128;
     s.a2 = N * 12 * 12 * 128; s.a3 = N * 12 * 12 * 256; s.a4 = N * 6 * 6 * 256; s.pool = N * 256; s.fc1 = N * 256;
     s.m1 = 2 * N * mlp_max; s.feat = N * 512; s.f = N * 256; s.gi = N * 768; s.gh = T * 384; s.l0 = N * 256; s.l1 = N * 256;
     // Winograd planes of the 24x24 layer (36 positions x 36 tiles x 128 channels); the 12x12 layer's fit too
@@ -658,7 +674,7 @@ HeadWs head_sizes(int64_t N, int64_t T, int64_t mlp_max, bool wino) {
 int64_t mm_head_workspace_bytes(mm_head_t* h, int64_t bs, int64_t T) {
     using mm::Bump;
     if (!h || bs < 0 || T < 0) return MM_ERR_INVALID_ARG;
-    const HeadWs s = head_sizes(bs * T, T, h->mlp_max, h->winograd != 0);
+    const HeadWs s = head_sizes(bs * T, T, h->mlp_max, h->winograd != 0, h->pc);
     const int64_t all[] = {s.p0n, s.a0, s.cat, s.a1, s.a2, s.a3, s.a4, s.pool, s.fc1, s.m1, s.feat, s.f, s.gi, s.gh, s.l0, s.l1, s.wv};
     int64_t tot = 0;
     for (int64_t v : all) tot += Bump::size_of(v);
@@ -676,7 +692,7 @@ int mm_head_forward(mm_head_t* h, const float* phase_0, const float* phase_1, in
     MM_CHECK_DEVICE(h);
     hipStream_t s = (hipStream_t)stream_;
     const int N = (int)N64;
-    const HeadWs z = head_sizes(N64, T, h->mlp_max, h->winograd != 0);
+    const HeadWs z = head_sizes(N64, T, h->mlp_max, h->winograd != 0, h->pc);
     Bump ws(workspace, workspace_bytes);
     float* p0n = ws.take(z.p0n); float* a0 = ws.take(z.a0); float* cat = ws.take(z.cat); float* a1 = ws.take(z.a1);
     float* a2 = ws.take(z.a2); float* a3 = ws.take(z.a3); float* a4 = ws.take(z.a4); float* pool = ws.take(z.pool);
@@ -687,25 +703,26 @@ int mm_head_forward(mm_head_t* h, const float* phase_0, const float* phase_1, in
 #define MM_TRY(x) do { rc = (x); if (rc != MM_OK) return rc; } while (0)
     // ---- temporal stream: PhaseNet (mimamo_net.py:79-92)
     const float* x0 = phase_0;
+    const int pc = h->pc, catc = 64 + pc;      // 24 / 88 for the published num_phase = 12
     if (!phase_nhwc) {
-        MM_TRY(nchw_to_nhwc(phase_0, p0n, N64, 24, 48 * 48, 24, 0, 24, s));
-        MM_TRY(nchw_to_nhwc(phase_1, cat, N64, 24, 24 * 24, 88, 64, 24, s));  // torch.cat([conv1, level1], dim=1) (:85)
+        MM_TRY(nchw_to_nhwc(phase_0, p0n, N64, pc, 48 * 48, pc, 0, pc, s));
+        MM_TRY(nchw_to_nhwc(phase_1, cat, N64, pc, 24 * 24, catc, 64, pc, s));  // torch.cat([conv1, level1], dim=1) (:85)
         x0 = p0n;
     } else if (phase_nhwc == 2) {
-        // phase_1 IS the concat buffer [N,24,24,88] with the level-1 channels already at 64..87 (written
+        // phase_1 IS the concat buffer [N,24,24,64+pc] with the level-1 channels already at 64.. (written
         // there by mm_phase_diff_frames); conv[1] fills channels 0..63 in place.
         cat = const_cast<float*>(phase_1);
     } else {
-        // phase_1 given as [N,24,24,24] NHWC: place it behind the 64 conv channels
-        MM_HIP(hipMemcpy2DAsync(cat + 64, 88 * sizeof(float), phase_1, 24 * sizeof(float), 24 * sizeof(float),
+        // phase_1 given as [N,24,24,pc] NHWC: place it behind the 64 conv channels
+        MM_HIP(hipMemcpy2DAsync(cat + 64, catc * sizeof(float), phase_1, pc * sizeof(float), pc * sizeof(float),
                                 (size_t)N64 * 24 * 24, hipMemcpyDeviceToDevice, s));
     }
-    MM_TRY(run_layer(h->conv[0], x0, N, 48, 48, 24, 0, a0, 64, 0, nullptr, 0, s));
-    MM_TRY(run_layer(h->conv[1], a0, N, 48, 48, 64, 0, cat, 88, 0, nullptr, 0, s));
+    MM_TRY(run_layer(h->conv[0], x0, N, 48, 48, pc, 0, a0, 64, 0, nullptr, 0, s));
+    MM_TRY(run_layer(h->conv[1], a0, N, 48, 48, 64, 0, cat, catc, 0, nullptr, 0, s));
     // the fused Winograd kernel declines (MM_ERR_UNSUPPORTED) what its 32-bit plane offsets cannot address: direct form then
     rc = MM_ERR_UNSUPPORTED;
     if (h->winograd && h->conv[2].wino_u4) rc = run_layer_wino(h->conv[2], cat, N, 24, 24, a1, wv, nullptr, 5, s);   // K = 88 padded to 128
-    if (rc == MM_ERR_UNSUPPORTED) rc = run_layer(h->conv[2], cat, N, 24, 24, 88, 0, a1, 128, 0, nullptr, 0, s);
+    if (rc == MM_ERR_UNSUPPORTED) rc = run_layer(h->conv[2], cat, N, 24, 24, catc, 0, a1, 128, 0, nullptr, 0, s);
     if (rc != MM_OK) return rc;
     MM_TRY(run_layer(h->conv[3], a1, N, 24, 24, 128, 0, a2, 128, 0, nullptr, 0, s));
     rc = MM_ERR_UNSUPPORTED;

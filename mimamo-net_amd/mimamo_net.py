@@ -15,10 +15,13 @@ class Two_Stream_RNN(object):
     def __init__(self, mlp_hidden_units=[2048, 256, 256], dropout=0.5, label_name='arousal_valence', num_phase=12):
         """Arguments as api/mimamo_net.py:97-122.  label_name in {'arousal', 'valence', 'arousal_valence'} sets the width
         of the output layer (len(label_name.split('_')), :120-122); mlp_hidden_units = [feature width, hidden..., 256]
-        (the reference's MLP asserts the last entry, :12; here every entry must also be a multiple of 4).  num_phase != 12
-        changes PhaseNet's input channels and is not built into the library."""
-        if num_phase != 12:
-            raise NotImplementedError("this build implements PhaseNet for num_phase=12 (api/tester.py:28)")
+        (the reference's MLP asserts the last entry, :12; here every entry must also be a multiple of 4).  num_phase sets
+        PhaseNet's input channels, 2 * num_phase per level (:112); even values up to 32 are built (16-byte channel groups)."""
+        num_phase = int(num_phase)
+        if num_phase < 1:
+            raise ValueError("num_phase must be positive")
+        if num_phase % 2 or num_phase > 32:
+            raise NotImplementedError("num_phase must be even and <= 32 in this build (2 * num_phase channels in groups of 4)")
         self.mlp_units = tuple(int(u) for u in mlp_hidden_units)
         assert len(self.mlp_units) - 1 > 0          # api/mimamo_net.py:11
         assert self.mlp_units[-1] == 256            # api/mimamo_net.py:12
@@ -54,6 +57,10 @@ class Two_Stream_RNN(object):
             if tuple(state_dict[k].shape)[0] != self.n_out:
                 raise RuntimeError("Error(s) in loading state_dict for Two_Stream_RNN: size mismatch for %s: checkpoint has %d "
                                    "outputs, label_name=%r needs %d" % (k, tuple(state_dict[k].shape)[0], self.label_name, self.n_out))
+        for k, shape in weights.two_stream_shapes(self.mlp_units, self.num_phase, self.n_out).items():
+            if tuple(state_dict[k].shape) != shape:     # what nn.Module.load_state_dict reports (e.g. a num_phase=12 checkpoint into num_phase=6)
+                raise RuntimeError("Error(s) in loading state_dict for Two_Stream_RNN: size mismatch for %s: copying a param with "
+                                   "shape %s from checkpoint, the shape in current model is %s" % (k, tuple(state_dict[k].shape), shape))
         self._state = {k: v for k, v in state_dict.items()}
         self._blob = weights.two_stream_blob(weights.widen_classifier(state_dict) if self.n_out == 1 else state_dict, self.mlp_units)
         self._release()
@@ -106,19 +113,19 @@ class Two_Stream_RNN(object):
             h = ctypes.c_void_p()
             with torch.cuda.device(self.device):
                 units = (ctypes.c_int * len(self.mlp_units))(*self.mlp_units)
-                rc = _lib.lib().mm_head_create_mlp(ctypes.byref(h), self._blob.ctypes.data_as(ctypes.c_void_p), self._blob.size,
-                                                   len(self.mlp_units), units)
-            _lib.check(rc, "mm_head_create_mlp")
+                rc = _lib.lib().mm_head_create_cfg(ctypes.byref(h), self._blob.ctypes.data_as(ctypes.c_void_p), self._blob.size,
+                                                   len(self.mlp_units), units, self.num_phase)
+            _lib.check(rc, "mm_head_create_cfg")
             self._handle = h
         return self._handle
 
     # -- forward ---------------------------------------------------------------------------------
     def forward(self, phase_data, rgb_data, phase_layout="nchw"):
-        """phase_data = [phase_0 [bs,T,24,48,48], phase_1 [bs,T,24,24,24]], rgb_data [bs,T,mlp_hidden_units[0]] -> [bs,T,n_out]
-        (n_out = 2 for 'arousal_valence', 1 for 'arousal' / 'valence').
+        """phase_data = [phase_0 [bs,T,C,48,48], phase_1 [bs,T,C,24,24]] with C = 2 * num_phase (24), rgb_data
+        [bs,T,mlp_hidden_units[0]] -> [bs,T,n_out] (n_out = 2 for 'arousal_valence', 1 for 'arousal' / 'valence').
 
-        phase_layout: "nchw" (reference), "nhwc" ([bs*T,48,48,24] / [bs*T,24,24,24]) or "nhwc_cat"
-        (phase_1 already at channels 64..87 of a [bs*T,24,24,88] buffer, completed in place).
+        phase_layout: "nchw" (reference), "nhwc" ([bs*T,48,48,C] / [bs*T,24,24,C]) or "nhwc_cat"
+        (phase_1 already at channels 64..64+C of a [bs*T,24,24,64+C] buffer, completed in place).
         The GRU recurrence runs over dim 0 (bs) with T as its batch (api/mimamo_net.py:119,139)."""
         if self.training:
             raise NotImplementedError("training mode")
@@ -130,12 +137,13 @@ class Two_Stream_RNN(object):
                 raise RuntimeError("inputs must be on the ROCm device; this build has no CPU path")
             assert t.dtype == torch.float32
         mode = {"nchw": 0, "nhwc": 1, "nhwc_cat": 2}[phase_layout]
+        C = 2 * self.num_phase
         if mode == 0:
-            assert tuple(phase_0.shape) == (bs, T, 24, 48, 48) and tuple(phase_1.shape) == (bs, T, 24, 24, 24)
+            assert tuple(phase_0.shape) == (bs, T, C, 48, 48) and tuple(phase_1.shape) == (bs, T, C, 24, 24)
         elif mode == 1:
-            assert tuple(phase_0.shape) == (bs * T, 48, 48, 24) and tuple(phase_1.shape) == (bs * T, 24, 24, 24)
+            assert tuple(phase_0.shape) == (bs * T, 48, 48, C) and tuple(phase_1.shape) == (bs * T, 24, 24, C)
         else:
-            assert tuple(phase_0.shape) == (bs * T, 48, 48, 24) and tuple(phase_1.shape) == (bs * T, 24, 24, 88)
+            assert tuple(phase_0.shape) == (bs * T, 48, 48, C) and tuple(phase_1.shape) == (bs * T, 24, 24, 64 + C)
         assert rgb_data.size(2) == self.mlp_units[0]
         phase_0, phase_1, rgb = phase_0.contiguous(), phase_1.contiguous(), rgb_data.contiguous()
         out = torch.empty((bs, T, 2), dtype=torch.float32, device=rgb.device)

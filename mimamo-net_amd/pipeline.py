@@ -22,17 +22,29 @@ from .resnet50_extractor import Resnet50_Extractor
 
 
 class HotPath(object):
+    PUBLISHED = (12, 48, 4, 2, 2, (1, 2))      # num_phase, phase_size, height, nbands, scale_factor, extract_level (api/tester.py:28-32)
+
     def __init__(self, head_state_dict, resnet_state_dict, device=None, length=64, stride=64, num_phase=12,
-                 batch_size=64, max_frames_per_call=4096, upload_chunk_frames=1024):
+                 batch_size=64, max_frames_per_call=4096, upload_chunk_frames=1024, phase_size=48, height=4, nbands=2,
+                 scale_factor=2, extract_level=(1, 2), model_num_phase=12):
+        """model_num_phase: num_phase of the Two_Stream_RNN the checkpoint belongs to.  The reference's Tester always builds
+        Two_Stream_RNN() with its default (api/tester.py:44), whatever num_phase its sampler uses -- so a non-published
+        sampler / pyramid configuration only runs there (and here) when it still hands PhaseNet 24 channels at 48x48 and
+        24x24, e.g. nbands=4 with num_phase=6."""
         self.device = torch.device('cuda', torch.cuda.current_device()) if device is None else torch.device(device)
         self.length, self.stride, self.num_phase, self.batch_size = length, stride, num_phase, batch_size
         self.max_frames_per_call = int(max_frames_per_call)
+        self.phase_size = int(phase_size)
+        levels = tuple(extract_level) if not isinstance(extract_level, int) else (extract_level,)
+        # the fused kernels (one pyramid per unique frame) implement the published configuration; anything else runs the
+        # reference's windowed form on the general pyramid + generic extract kernels (13x redundant like the reference, not tuned)
+        self.fused = (int(num_phase), self.phase_size, int(height), int(nbands), int(scale_factor), levels) == self.PUBLISHED
         self.upload_chunk_frames = max(1, int(upload_chunk_frames))   # host-resident input: frames per double-buffered upload
         self._feeders = {}
-        self.pde = Phase_Difference_Extractor(4, 2, 2, [1, 2], False)
+        self.pde = Phase_Difference_Extractor(height, nbands, scale_factor, list(levels) if len(levels) > 1 else levels[0], False)
         self.resnet = Resnet50_Extractor(state_dict=resnet_state_dict, device=self.device,
                                          max_frames_per_call=self.max_frames_per_call)
-        self.head = Two_Stream_RNN().load_state_dict(head_state_dict).eval().to(self.device)
+        self.head = Two_Stream_RNN(num_phase=model_num_phase).load_state_dict(head_state_dict).eval().to(self.device)
         self._pre = None
 
     # ---- index plan for a set of videos (host, once) ---------------------------------------------
@@ -114,7 +126,7 @@ class HotPath(object):
         self._check(plan, frames_u8.shape[0], independent_clips)
         if self._pre is None:
             from .preprocess import FramePreprocessor
-            self._pre = FramePreprocessor(device=self.device)
+            self._pre = FramePreprocessor(phase_size=self.phase_size, device=self.device)
         if not frames_u8.is_cuda:
             return self._forward_u8_host(frames_u8, plan)
         N, step = frames_u8.shape[0], self.max_frames_per_call
@@ -174,11 +186,21 @@ class HotPath(object):
         groups = plan["groups"]
         out = None
         for g in groups:
-            p0, cat = self.pde.phase_diff_frames(gray[g["f0"]:g["f1"]], g["ids"], nhwc=True, out1_cstride=88, out1_coffset=64,
-                                                 ids_checked=True)
             rgb_rows = (feats[g["row_first"]:g["row_first"] + g["n"]] if g["rows"] is None
                         else feats.index_select(0, g["rows"]))
-            o = self.head.forward([p0, cat], rgb_rows.view(g["bs"], g["T"], 2048), phase_layout="nhwc_cat").view(-1, 2)
+            if self.fused:
+                p0, cat = self.pde.phase_diff_frames(gray[g["f0"]:g["f1"]], g["ids"], nhwc=True, out1_cstride=88, out1_coffset=64,
+                                                     ids_checked=True)
+                o = self.head.forward([p0, cat], rgb_rows.view(g["bs"], g["T"], 2048), phase_layout="nhwc_cat").view(-1, 2)
+            else:
+                # the reference's own form (api/tester.py:122-139): windows gathered per row, pyramid per window frame
+                from .phase_difference_extractor import phase_diff_output
+                win = gray[g["f0"]:g["f1"]].index_select(0, g["ids"].reshape(-1).long())
+                win = win.view(g["bs"], g["T"], self.num_phase + 1, self.phase_size, self.phase_size)
+                levels = phase_diff_output(win, self.pde)
+                if len(levels) != 2:
+                    raise ValueError("Two_Stream_RNN takes two pyramid levels (api/mimamo_net.py:133); extract_level gave %d" % len(levels))
+                o = self.head.forward([levels[0].contiguous(), levels[1].contiguous()], rgb_rows.view(g["bs"], g["T"], 2048)).view(-1, 2)
             if len(groups) == 1 and g["dest"] is None:
                 return o
             if out is None:

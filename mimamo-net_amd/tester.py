@@ -24,8 +24,11 @@ class Tester(object):
                  num_phase=12, phase_size=48, length=64, stride=64,
                  height=4, nbands=2, scale_factor=2, extract_level=[1, 2],
                  head_state_dict=None, resnet_state_dict=None, device=None):
-        if (num_phase, phase_size, height, nbands, scale_factor, list(extract_level)) != (12, 48, 4, 2, 2, [1, 2]):
-            raise NotImplementedError("only the published configuration (api/tester.py:28-32) is implemented")
+        """Keywords as api/tester.py:15-33.  The published configuration (num_phase 12, phase_size 48, height 4, nbands 2,
+        scale_factor 2, levels [1, 2]) runs on the fused kernels; other sampler / pyramid configurations are forwarded to
+        the general pyramid + generic extract kernels in the reference's windowed form.  Like the reference, the model is
+        always Two_Stream_RNN() (api/tester.py:44): a configuration only runs if it hands PhaseNet 2 x 12 channels at 48 x 48
+        and 24 x 24 (e.g. nbands=4, num_phase=6); anything else fails at the model's input check, as it does there."""
         self.batch_size, self.workers, self.save_size = batch_size, workers, save_size
         self.num_phase, self.phase_size, self.length, self.stride = num_phase, phase_size, length, stride
         self.label_name = ['valence', 'arousal']  # api/tester.py:52
@@ -38,7 +41,8 @@ class Tester(object):
             pth = os.path.join(os.path.abspath(benchmark_dir), 'ferplus', model_name + '.pth')
             assert os.path.exists(pth), 'benchmark_dir must exits'
             resnet_state_dict = torch.load(pth, map_location='cpu')
-        self.hot = HotPath(head_state_dict, resnet_state_dict, device, length, stride, num_phase, batch_size)
+        self.hot = HotPath(head_state_dict, resnet_state_dict, device, length, stride, num_phase, batch_size, phase_size=phase_size,
+                           height=height, nbands=nbands, scale_factor=scale_factor, extract_level=tuple(extract_level))
         self.device = self.hot.device
         self.phase_difference_extractor = self.hot.pde
         self.resnet50_extractor = self.hot.resnet

@@ -185,11 +185,24 @@ _FLOAT_KEYS = {}
 
 
 def two_stream_float_keys(mlp_units=MLP_PUBLISHED):
-    """state_dict keys of Two_Stream_RNN in module order, without the int64 BN counters."""
+    """state_dict keys of Two_Stream_RNN in module order, without the int64 BN counters (the key set does not depend on
+    num_phase, only two tensor shapes do)."""
     mlp_units = tuple(int(u) for u in mlp_units)
     if mlp_units not in _FLOAT_KEYS:
         _FLOAT_KEYS[mlp_units] = [k for k in make_two_stream_state_dict(0, mlp_units=mlp_units) if not k.endswith("num_batches_tracked")]
     return _FLOAT_KEYS[mlp_units]
+
+
+_SHAPES = {}
+
+
+def two_stream_shapes(mlp_units=MLP_PUBLISHED, num_phase=12, n_out=2):
+    """{key: shape} of the float tensors for a configuration (what load_state_dict checks a checkpoint against)."""
+    key = (tuple(int(u) for u in mlp_units), int(num_phase), int(n_out))
+    if key not in _SHAPES:
+        _SHAPES[key] = {k: tuple(np.shape(v)) for k, v in make_two_stream_state_dict(0, key[1], key[2], key[0]).items()
+                        if not k.endswith("num_batches_tracked")}
+    return _SHAPES[key]
 
 
 def widen_classifier(state_dict):

@@ -339,12 +339,54 @@ def g8_scfpyr_full(ref):
     np.savez_compressed(os.path.join(HERE, "scfpyr_full.npz"), **out)
 
 
+def nondefault_windows(T=4, P=7):
+    """[1,T,P,48,48]: T consecutive 7-frame windows of one textured clip (num_phase = 6)."""
+    clip = synthetic.textured_gray(T + P - 1, 48, seed=61)
+    return np.stack([clip[t:t + P] for t in range(T)])[None]
+
+
+def g11_nondefault(ref):
+    """A configuration other than api/tester.py:28-32's, through the real reference:
+    (a) Two_Stream_RNN(num_phase=6): PhaseNet with 12 input channels per level (api/mimamo_net.py:97-112);
+    (b) the Tester's chain with a 4-band pyramid and 7-frame windows -- nbands * num_phase = 24 channels at 48x48 and 24x24,
+        which is what its default Two_Stream_RNN() takes (api/tester.py:28-45,122-139): phase_diff_output + model."""
+    out = {"weight_seed_a": 5, "weight_seed_b": 3}
+    torch.set_default_dtype(torch.float32)
+    sd = weights.make_two_stream_state_dict(seed=5, num_phase=6)
+    model = ref.Two_Stream_RNN(num_phase=6)
+    model.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, strict=True)
+    model.eval()
+    p0 = weights.det_uniform("nd.p0", (2, 3, 12, 48, 48), -1.5, 1.5, 71)
+    p1 = weights.det_uniform("nd.p1", (2, 3, 12, 24, 24), -1.5, 1.5, 71)
+    rgb = weights.det_uniform("nd.rgb", (2, 3, 2048), 0.0, 2.0, 71)
+    with torch.no_grad():
+        out["a_out"] = model([torch.from_numpy(p0), torch.from_numpy(p1)], torch.from_numpy(rgb)).numpy()
+    w = nondefault_windows()
+    pde = ref.Phase_Difference_Extractor(4, 4, 2, [1, 2], False)
+    q0, q1 = ref.Tester.phase_diff_output(None, torch.from_numpy(w), pde)
+    torch.set_default_dtype(torch.float32)
+    sd = weights.make_two_stream_state_dict(seed=3)
+    model = ref.Two_Stream_RNN()
+    model.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, strict=True)
+    model.eval()
+    rgb_b = weights.det_uniform("nd.rgb_b", (1, w.shape[1], 2048), 0.0, 2.0, 72)
+    with torch.no_grad():
+        out["b_out"] = model([q0.float(), q1.float()], torch.from_numpy(rgb_b)).numpy()
+    out["b_phase_0"] = q0.numpy()[0].astype(np.float32)
+    out["b_phase_1"] = q1.numpy()[0].astype(np.float32)
+    np.savez_compressed(os.path.join(HERE, "nondefault.npz"), **out)
+    print("G11", out["a_out"].reshape(-1, 2)[:2], q0.shape, q1.shape, out["b_out"].reshape(-1, 2)[:2])
+
+
 if __name__ == "__main__":
     if sys.argv[1:] in ([], ["g5"]):
         g5_resnet50_hf()   # before ref_shim.load(): its torchvision stub confuses transformers' optional-dependency probe
         if sys.argv[1:]:
             sys.exit(0)
     ref = ref_shim.load()
+    if sys.argv[1:] == ["g11"]:
+        g11_nondefault(ref)
+        sys.exit(0)
     if sys.argv[1:] == ["g10"]:
         g10_train_phase(ref)
         sys.exit(0)
@@ -363,4 +405,5 @@ if __name__ == "__main__":
     g8_scfpyr_full(ref)
     g9_phase_generic(ref)
     g10_train_phase(ref)
+    g11_nondefault(ref)
     os.system("ls -la %s" % HERE)

@@ -208,6 +208,32 @@ def test_head_full_clip_vs_oracle_and_layouts(head, oracle, dev):
         assert torch.equal(head.forward([n0, cat], trgb, phase_layout="nhwc_cat"), y)
 
 
+def test_head_with_another_num_phase_vs_real_reference(golden, oracle, dev):
+    """Two_Stream_RNN(num_phase=6): PhaseNet takes 12 channels per level (api/mimamo_net.py:97-112).  Outputs of the real
+    reference class frozen in tests/golden/nondefault.npz (make_golden.py g11); odd / oversized num_phase is refused, and a
+    num_phase=12 checkpoint does not load into it."""
+    from mimamo_net_amd.mimamo_net import Two_Stream_RNN
+    g = golden("nondefault")
+    sd6 = weights.make_two_stream_state_dict(seed=int(g["weight_seed_a"]), num_phase=6)
+    m = Two_Stream_RNN(num_phase=6).load_state_dict(sd6).eval().to(dev)
+    p0 = weights.det_uniform("nd.p0", (2, 3, 12, 48, 48), -1.5, 1.5, 71)
+    p1 = weights.det_uniform("nd.p1", (2, 3, 12, 24, 24), -1.5, 1.5, 71)
+    rgb = weights.det_uniform("nd.rgb", (2, 3, 2048), 0.0, 2.0, 71)
+    t = lambda a: torch.from_numpy(a).to(dev)
+    y = m([t(p0), t(p1)], t(rgb)).cpu().numpy()
+    err = np.abs(y - g["a_out"]).max()
+    print("num_phase=6 head vs real reference: %.2e" % err)
+    assert err < OUT_ATOL and err < 6e-5, err          # contract 1e-4; regression bound ~3x the 2e-5 seen on the published head
+    # channels-last inputs (what a fused producer would hand over) give the same result
+    y2 = m([t(p0).view(6, 12, 48, 48).permute(0, 2, 3, 1).contiguous(), t(p1).view(6, 12, 24, 24).permute(0, 2, 3, 1).contiguous()], t(rgb),
+           phase_layout="nhwc").cpu().numpy()
+    assert np.abs(y2 - y).max() < 1e-6
+    with pytest.raises(NotImplementedError):
+        Two_Stream_RNN(num_phase=7)
+    with pytest.raises(RuntimeError, match="size mismatch"):
+        Two_Stream_RNN(num_phase=6).load_state_dict(weights.make_two_stream_state_dict(seed=0))
+
+
 def test_head_bs1_is_frame_permutation_equivariant(head, dev):
     """With bs=1 the GRU sees seq_len 1: frames are independent."""
     p0, p1, rgb = (torch.from_numpy(a).to(dev) for a in _head_inputs(1, 16, 5))

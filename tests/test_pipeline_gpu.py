@@ -274,3 +274,46 @@ def test_host_resident_frames_stream_in_chunks_with_identical_rows(tester):
             assert torch.equal(got, want)
     finally:
         tester.hot.upload_chunk_frames = keep
+
+
+def test_tester_with_a_non_published_pyramid_configuration(golden, oracle):
+    """Tester forwards its sampler / pyramid keywords (api/tester.py:15-33): a 4-band pyramid over 7-frame windows still hands
+    the default Two_Stream_RNN() its 24 channels per level (api/tester.py:44-45), so it runs -- in the reference and here, on the
+    general pyramid + generic extract kernels.  (a) phase_diff_output + model against the real reference's outputs
+    (tests/golden/nondefault.npz); (b) a whole video through Tester.test_frames against the oracle with the same keywords;
+    (c) a configuration whose channel count does not fit the model fails at the model's input check."""
+    from mimamo_net_amd.tester import Tester
+    from mimamo_net_amd.phase_difference_extractor import phase_diff_output
+    g = golden("nondefault")
+    head_sd = weights.make_two_stream_state_dict(seed=int(g["weight_seed_b"]))
+    resnet_sd = weights.make_resnet50_state_dict(seed=0)
+    t = Tester(model_path=None, batch_size=64, head_state_dict=head_sd, resnet_state_dict=resnet_sd, device="cuda:0",
+               num_phase=6, nbands=4)
+    assert not t.hot.fused
+    clip = synthetic.textured_gray(10, 48, seed=61)
+    w = np.stack([clip[i:i + 7] for i in range(4)])[None]
+    q0, q1 = phase_diff_output(torch.from_numpy(w).to(t.device), t.phase_difference_extractor)
+    for got, want in ((q0, g["b_phase_0"]), (q1, g["b_phase_1"])):
+        d = np.abs(got.cpu().numpy()[0] - want)
+        print("4-band / 7-frame windows vs real reference: max %.2e" % d.max())
+        assert d.max() < 1e-3 and np.quantile(d, 0.9999) < 3e-4 and d.max() < 1e-4       # contract, then regression bound
+    rgb_b = torch.from_numpy(weights.det_uniform("nd.rgb_b", (1, 4, 2048), 0.0, 2.0, 72)).to(t.device)
+    y = t.model([q0, q1], rgb_b).cpu().numpy()
+    assert np.abs(y - g["b_out"]).max() < OUT_ATOL
+    # (b) a 70-frame video: snippets [0,64) and [6,70), windows of 7 clamped frames
+    video = synthetic.make_clip_u8(80, 70)
+    res = t.test_frames([video], names=["v"])["v"].values
+    gray, rgb = synthetic.preprocess_host(video)
+    n = len(video)
+    ranges = oracle.snippet_ranges(n, 64, 64)
+    feats = oracle.resnet50_pool5(resnet_sd, rgb)
+    ph = np.stack([gray[oracle.window_ids(s, e, n, 6)] for s, e in ranges])
+    p0, p1 = oracle.phase_diff_output(ph, height=4, nbands=4)
+    want = oracle.assemble(list(oracle.two_stream_forward(head_sd, p0, p1, np.stack([feats[s:e] for s, e in ranges]))), ranges)
+    err = np.abs(res - want).max()
+    print("Tester(num_phase=6, nbands=4) 70-frame video vs oracle: %.2e" % err)
+    assert res.shape == (70, 2) and err < OUT_ATOL
+    # (c) 2 bands x 6 differences = 12 channels: the default model refuses them
+    t2 = Tester(model_path=None, batch_size=64, head_state_dict=head_sd, resnet_state_dict=resnet_sd, device="cuda:0", num_phase=6)
+    with pytest.raises(AssertionError):
+        t2.test_frames([video[:16]])
