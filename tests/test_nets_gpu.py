@@ -14,6 +14,11 @@ pytestmark = pytest.mark.gpu
 
 OUT_ATOL = 1e-4        # valence/arousal tolerance stated by BASELINE.json north_star
 POOL5_RTOL = 1e-5      # pool5 features, relative to the feature scale
+# Regression bounds next to the contract: ~3x what rounds 1-3 have shown on these inputs (pool5 max rel 4e-7 .. 7e-7, mean rel
+# 4e-8 .. 6e-8 for every Winograd form; valence/arousal 3e-7 .. 5e-7 in the stress test).  They catch a kernel that silently lost
+# digits while still inside the reference-derived tolerance.
+POOL5_TIGHT_MAX = 2.5e-6
+POOL5_TIGHT_MEAN = 2.5e-7
 
 
 @pytest.fixture(scope="module")
@@ -281,6 +286,7 @@ def test_resnet50_pool5_vs_oracle(resnet, oracle, dev):
     rel = np.abs(got - want).max() / scale
     assert rel < POOL5_RTOL * 10, rel          # hard bound
     assert np.abs(got - want).mean() / scale < POOL5_RTOL, np.abs(got - want).mean() / scale
+    assert rel < POOL5_TIGHT_MAX and np.abs(got - want).mean() / scale < POOL5_TIGHT_MEAN, ("regression bound", rel)
     assert (got >= 0).all() and got.std() > 0
     # batch composition does not change a frame's features (no cross-frame coupling, tile choice aside)
     one = resnet.get_vec(torch.from_numpy(x[1:2]).to(dev)).cpu().numpy()
@@ -310,6 +316,7 @@ def test_resnet50_against_independent_third_party_implementation(resnet, golden,
             mx, mean = np.abs(got - want).max() / scale, np.abs(got - want).mean() / scale
             print("vs HF ResNetModel, winograd %d: max rel %.2e mean rel %.2e" % (mode, mx, mean))
             assert mx < POOL5_RTOL * 10 and mean < POOL5_RTOL, (mode, mx, mean)
+            assert mx < POOL5_TIGHT_MAX and mean < POOL5_TIGHT_MEAN, ("regression bound", mode, mx, mean)
     finally:
         resnet.set_winograd(True)
 
@@ -334,6 +341,7 @@ def test_resnet50_winograd_and_direct_paths_agree(resnet, oracle, dev):
         print("winograd mode %d: pool5 max rel %.2e mean rel %.2e" % (mode, mx, mean))
         assert mx < POOL5_RTOL * 10, (mode, mx)
         assert mean < POOL5_RTOL, (mode, mean)
+        assert mx < POOL5_TIGHT_MAX and mean < POOL5_TIGHT_MEAN, ("regression bound", mode, mx, mean)
 
 
 def test_resnet50_full_batch_properties(resnet, dev):
@@ -463,6 +471,8 @@ def test_winograd_error_where_it_can_hurt(oracle, dev, case):
     assert d[0] < 1e-4 and d[1] < 1e-5 and d[2] < OUT_ATOL, d                  # the direct form holds the stated bounds
     assert w2[0] < 1e-4 and w2[1] < 1e-5 and w2[2] < OUT_ATOL, w2
     assert w4[0] < 1e-4 and w4[1] < 1e-5 and w4[2] < OUT_ATOL, w4              # F(4x4,3x3) stays the default only if it does too
+    for w in (d, w2, w4, w5):
+        assert w[0] < POOL5_TIGHT_MAX and w[1] < POOL5_TIGHT_MEAN and w[2] < 2e-6, ("regression bound", w)
 
 
 @pytest.mark.parametrize("units", [[2048, 512, 256], [1024, 256], [2048, 384, 128, 256]])

@@ -2,7 +2,7 @@
 # HBM/fabric traffic per bench step from rocprofv3 PMC counters, collected as MI355X_MICROARCH.md prescribes: FETCH_SIZE and
 # WRITE_SIZE in SEPARATE passes (TCC slot budget), --kernel-trace only, FETCH_SIZE doubled (gfx950 reports half the bytes of
 # 16-byte-per-lane streaming reads; checked on a 1x1 conv whose operand read is known).  Writes
-# gpurun_out/r02_conv_traffic_<clips>clips.json and gpurun_out/r02_phase_traffic_<clips>clips.json, each stamped with the hash of
+# gpurun_out/r03_conv_traffic_<clips>clips.json and gpurun_out/r03_phase_traffic_<clips>clips.json, each stamped with the hash of
 # the kernel sources they were measured on (bench.py only quotes a summary whose hash matches).  usage: tools/pmc_traffic.sh [clips]
 CLIPS=${1:-32}
 STEPS=2; WARM=1
@@ -21,7 +21,7 @@ sys.path.insert(0, root)
 import bench
 nsteps = steps + warm + 2          # + the two single-stream steps of the roofline leg
 groups = {"conv": ("conv_mfma_kernel", "wino_fused_kernel"), "winograd_transforms": ("wino_in", "wino_out"),
-          "pyramid": ("pyramid_kernel",), "phase_frames_windows": ("phase_frame_kernel", "phase_window2_kernel")}
+          "pyramid": ("pyramid_kernel", "pyramid_frame_kernel"), "phase_frames_windows": ("phase_window2_kernel",)}
 tot = {g: {} for g in groups}
 for c in ("FETCH_SIZE", "WRITE_SIZE"):
     f = glob.glob("/tmp/bt_%s/**/*counter_collection.csv" % c, recursive=True)[0]
@@ -40,7 +40,7 @@ conv = dict(common, bytes_per_step=bytes_per_step("conv"), kernels="conv_mfma_ke
             winograd_transforms_bytes_per_step=bytes_per_step("winograd_transforms"))
 phase = dict(common, bytes_per_step=bytes_per_step("pyramid") + bytes_per_step("phase_frames_windows"),
              pyramid_bytes_per_step=bytes_per_step("pyramid"), frames_windows_bytes_per_step=bytes_per_step("phase_frames_windows"))
-json.dump(conv, open(root + "/gpurun_out/r02_conv_traffic_%dclips.json" % clips, "w"), indent=1)
-json.dump(phase, open(root + "/gpurun_out/r02_phase_traffic_%dclips.json" % clips, "w"), indent=1)
+json.dump(conv, open(root + "/gpurun_out/r03_conv_traffic_%dclips.json" % clips, "w"), indent=1)
+json.dump(phase, open(root + "/gpurun_out/r03_phase_traffic_%dclips.json" % clips, "w"), indent=1)
 print(json.dumps(conv)); print(json.dumps(phase))
 PY
