@@ -27,8 +27,11 @@ with torch.no_grad():
     for clips in (1, 32, 256):
         n = clips * 64
         gray = torch.rand(n, 48, 48, device=dev)
-        plan = hot.plan([64] * clips)
-        dt = timeit(lambda: hot.pde.phase_diff_frames(gray, plan["groups"][0]["ids"], nhwc=True, out1_cstride=88, out1_coffset=64), 20)
+        # window ids of ALL clips (plan() splits the rows into head-call groups of 64 snippets: up to round 2 this tool handed
+        # over groups[0] only, i.e. at 256 clips the window kernels ran for the first 64 clips -- its 3.17 M frames/s was inflated)
+        import numpy as np
+        ids = torch.from_numpy(np.concatenate([sampler.window_ids(0, 64, 64) + 64 * c for c in range(clips)]).astype(np.int32)).to(dev)
+        dt = timeit(lambda: hot.pde.phase_diff_frames(gray, ids, nhwc=True, out1_cstride=88, out1_coffset=64, ids_checked=True), 20)
         print("   %4d clips (%6d frames): %.3f ms  %.2f M frames/s  %.0f GB/s algorithmic" % (clips, n, dt * 1e3, n / dt / 1e6, n * 285696 / dt / 1e9))
     print("configs[2]  ResNet50 pool5 extractor (fp32 NCHW batches resident in HBM)")
     for bs in (64, 256, 1024):
