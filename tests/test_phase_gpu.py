@@ -203,6 +203,30 @@ def test_full_size_properties(pde, dev):
     assert s0.abs().max() == 0 and s1.abs().max() == 0
 
 
+def test_phase_stage_is_deterministic_under_load(pde, dev):
+    """Chip-filling launches of the fused phase stage are bit-identical run to run and equal to the same clips computed in a small
+    launch (the per-frame kernel hands LDS rows between its waves with wave-level fences and re-tenants one LDS region per pass:
+    a missing barrier would show up here as a rare corrupted plane; frames and windows are independent, so batch size must not matter)."""
+    clips = 48
+    base = np.concatenate([synthetic.textured_gray(64, 48, seed=300 + c) for c in range(6)])
+    frames = torch.from_numpy(base).to(dev).repeat(clips // 6, 1, 1).contiguous()
+    n = clips * 64
+    one = torch.clamp(torch.arange(64, device=dev)[:, None] + torch.arange(-6, 7, device=dev)[None, :], 0, 63)
+    ids = (one[None] + 64 * torch.arange(clips, device=dev)[:, None, None]).reshape(n, 13).int().contiguous()
+    first = pde.phase_diff_frames(frames, ids, nhwc=True, out1_cstride=88, out1_coffset=64)
+    f0, f1 = first[0].clone(), first[1][..., 64:].clone()
+    for _ in range(12):
+        a0, a1 = pde.phase_diff_frames(frames, ids, nhwc=True, out1_cstride=88, out1_coffset=64)
+        assert torch.equal(a0, f0) and torch.equal(a1[..., 64:], f1)
+    for c in (0, 17, clips - 1):      # one clip alone: same rows
+        s0, s1 = pde.phase_diff_frames(frames[c * 64:(c + 1) * 64].contiguous(), one.int().contiguous(), nhwc=True, out1_cstride=88,
+                                       out1_coffset=64)
+        assert torch.equal(s0, f0[c * 64:(c + 1) * 64]) and torch.equal(s1[..., 64:], f1[c * 64:(c + 1) * 64])
+    # the six distinct clips repeat every 6 positions: every repetition must give the same rows
+    for c in range(6, clips):
+        assert torch.equal(f0[c * 64:(c + 1) * 64], f0[(c % 6) * 64:(c % 6 + 1) * 64])
+
+
 def test_degenerate_frames_stay_finite_and_match_oracle(pde, oracle, dev):
     """Spatially constant / all-zero frames have (numerically) zero band coefficients: magnitude = the reference's 1e-10
     EPS term, phase = atan2 of rounding noise.  Nothing may become NaN/Inf, and an all-zero clip gives exact zeros in
