@@ -82,6 +82,11 @@ def test_tester_reads_reference_directory_layout(tester, oracle, tmp_path):
     tester.resnet50_extractor.run(str(tmp_path / "utt_opface"), str(out_dir), video_name="utt")
     files = sorted(os.listdir(out_dir))
     assert files[0] == "00001.npy" and len(files) == 12 and np.load(str(out_dir / files[0])).shape == (2048,)
+    # run() decodes on the host and preprocesses 112 x 112 crops on the GPU: same features, bit for bit, as get_vec on the
+    # reference's host-side PIL preprocessing (utils/model_utils.py:29-39)
+    want = tester.resnet50_extractor.get_vec(sampler.load_rgb_batch(paths).to(tester.device)).cpu().numpy()
+    got = np.stack([np.load(str(out_dir / f)) for f in files])
+    np.testing.assert_array_equal(got, want)
     with pytest.raises(RuntimeError, match="aligned faces not found"):
         tester.test(str(tmp_path / "missing.mp4"))
 
