@@ -122,6 +122,86 @@ preproc_gray_kernel(const uint8_t* __restrict__ frames, int S, int G, int ksize,
     }
 }
 
+// ---- rgb, zero-bordered packed NHWC3 output (the stem's fastest input): one workgroup per (frame, 16 output rows).
+// The general kernel below evaluates the horizontal pass once per (output row, vertical tap): 16 rows x 2 taps = 32 evaluations per
+// output column for the 8-10 input rows a block really touches.  Here the block's input rows go through the horizontal pass ONCE
+// into LDS (uint8, what PIL stores between its passes), the vertical pass reads bytes from LDS, and every lane writes one float of
+// the packed row (row starts are only 4-byte aligned in the bordered layout): 256 contiguous bytes per wave store.
+constexpr int RGB_ROWS = 16, RGB_MAX_IN = 24;
+__global__ void __launch_bounds__(256)
+preproc_rgb3_kernel(const uint8_t* __restrict__ frames, int S, int R, int C, int ksize, const int* __restrict__ bounds,
+                    const int* __restrict__ kk, float mean0, float mean1, float mean2, float* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char hrow[];      // [n_in][C][3] uint8
+    const int64_t n = blockIdx.x;
+    const int row0 = blockIdx.y * RGB_ROWS;
+    const int off = (int)rintf((R - C) / 2.0f);  // CenterCrop: int(round((256-224)/2.)) = 16
+    const uint8_t* src = frames + n * (int64_t)S * S * 3;
+    const int CP = C + 6;
+    float* img = out + n * (int64_t)CP * CP * 3;
+    const int rows = min(RGB_ROWS, C - row0);
+    // the 3-pixel zero border of this block's rows (left / right), and the three full rows above / below by the first / last block
+    for (int i = threadIdx.x; i < rows * 18; i += 256) {
+        const int ry = i / 18, e = i - ry * 18;
+        img[((int64_t)(row0 + ry + 3) * CP + (e < 9 ? 0 : C + 3)) * 3 + (e < 9 ? e : e - 9)] = 0.f;
+    }
+    if (blockIdx.y == 0)
+        for (int i = threadIdx.x; i < 3 * CP * 3; i += 256) img[i] = 0.f;
+    if (blockIdx.y == gridDim.y - 1)
+        for (int i = threadIdx.x; i < 3 * CP * 3; i += 256) img[(int64_t)(C + 3) * CP * 3 + i] = 0.f;
+    // input rows this block's vertical taps touch
+    const int yy_first = row0 + off, yy_last = row0 + rows - 1 + off;
+    const int in_lo = bounds[yy_first * 2];
+    const int n_in = bounds[yy_last * 2] + bounds[yy_last * 2 + 1] - in_lo;
+    // horizontal pass, once per (input row, cropped output column)
+    for (int i = threadIdx.x; i < n_in * C; i += 256) {
+        const int r = i / C, cx = i - r * C;
+        const int xx = cx + off;
+        const int xmin = bounds[xx * 2], xcnt = bounds[xx * 2 + 1];
+        const int* kx = kk + xx * ksize;
+        const uint8_t* rowp = src + ((int64_t)(in_lo + r) * S + xmin) * 3;
+        int a0 = 1 << (PRECISION_BITS - 1), a1 = a0, a2 = a0;
+        for (int x = 0; x < xcnt; ++x) {
+            const int w = kx[x];
+            a0 += (int)rowp[x * 3] * w;
+            a1 += (int)rowp[x * 3 + 1] * w;
+            a2 += (int)rowp[x * 3 + 2] * w;
+        }
+        unsigned char* h = hrow + (r * C + cx) * 3;
+        h[0] = (unsigned char)clip8(a0); h[1] = (unsigned char)clip8(a1); h[2] = (unsigned char)clip8(a2);
+    }
+    // per-row vertical taps and the epilogue as a table: the reference's ToTensor (/255), *255.0, -mean are three separately rounded
+    // fp32 operations of a uint8 value -- 256 possible results per channel, evaluated once per block with contraction off
+    __shared__ int s_rel[RGB_ROWS], s_cnt[RGB_ROWS], s_k[RGB_ROWS][4];
+    __shared__ float s_lut[3][256];
+    if (threadIdx.x < rows) {
+        const int yy = row0 + threadIdx.x + off;
+        s_rel[threadIdx.x] = bounds[yy * 2] - in_lo;
+        s_cnt[threadIdx.x] = bounds[yy * 2 + 1];
+        for (int y = 0; y < 4; ++y) s_k[threadIdx.x][y] = y < ksize ? kk[yy * ksize + y] : 0;
+    }
+    for (int i = threadIdx.x; i < 768; i += 256) {
+#pragma clang fp contract(off)
+        const int c = i >> 8;
+        const float q = (float)(i & 255) / 255.0f;
+        const float m255 = q * 255.0f;
+        s_lut[c][i & 255] = m255 - (c == 0 ? mean0 : c == 1 ? mean1 : mean2);
+    }
+    __syncthreads();
+    // vertical pass: a lane owns up to three floats (columns fl = cx * 3 + c) of the packed row and walks the block's rows, so a
+    // wave store covers 256 contiguous bytes
+    const int RF = C * 3;
+    for (int fl = threadIdx.x; fl < RF; fl += 256) {
+        const float* lut = s_lut[fl % 3];
+        for (int ry = 0; ry < rows; ++ry) {
+            const unsigned char* hp = hrow + s_rel[ry] * RF + fl;
+            int acc = 1 << (PRECISION_BITS - 1);
+            const int cnt = s_cnt[ry];
+            for (int y = 0; y < cnt; ++y) acc += (int)hp[y * RF] * s_k[ry][y];
+            img[((int64_t)(row0 + ry + 3) * CP + 3) * 3 + fl] = lut[clip8(acc)];
+        }
+    }
+}
+
 // ---- rgb: bilinear S -> R, centre crop C, normalise.  grid (frames, row tiles of 16 output rows) -------
 __global__ void __launch_bounds__(256)
 preproc_rgb_kernel(const uint8_t* __restrict__ frames, int S, int R, int C, int ksize, const int* __restrict__ bounds,
@@ -281,7 +361,15 @@ int mm_preproc_forward(mm_preproc_t* h, const uint8_t* frames, int64_t n, float*
                            h->lan.ksize, h->d_lan_bounds, h->d_lan_kk, gray_out);
         MM_LAUNCH_CHECK();
     }
-    if (rgb_out) {
+    if (rgb_out && rgb_nchw == 2) {
+        // rows of the block after the horizontal pass: at most RGB_MAX_IN input rows x crop columns x 3 bytes of LDS
+        const int max_in = (int)((double)mm::RGB_ROWS * h->in_size / h->resize) + 4;
+        if (max_in > mm::RGB_MAX_IN || h->bil.ksize > 4) return MM_ERR_UNSUPPORTED;   // (a down-scaling resize: not the reference's 112 -> 256)
+        dim3 grid((unsigned)n, (unsigned)((h->crop + mm::RGB_ROWS - 1) / mm::RGB_ROWS));
+        hipLaunchKernelGGL(mm::preproc_rgb3_kernel, grid, dim3(256), max_in * h->crop * 3, s, frames, h->in_size, h->resize, h->crop,
+                           h->bil.ksize, h->d_bil_bounds, h->d_bil_kk, h->mean[0], h->mean[1], h->mean[2], rgb_out);
+        MM_LAUNCH_CHECK();
+    } else if (rgb_out) {
         dim3 grid((unsigned)n, (unsigned)((h->crop + 15) / 16));
         hipLaunchKernelGGL(mm::preproc_rgb_kernel, grid, dim3(256), 0, s, frames, h->in_size, h->resize, h->crop, h->bil.ksize,
                            h->d_bil_bounds, h->d_bil_kk, h->mean[0], h->mean[1], h->mean[2], rgb_out, rgb_nchw);
