@@ -338,6 +338,8 @@ def main():
         _cpu_worker(int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), sys.argv[5], int(sys.argv[6]) if len(sys.argv) > 6 else 0)
         return 0
     args = parse_args()
+    if args.stream_input and args.from_f32:
+        raise SystemExit("bench.py: --stream-input streams the uint8 boundary; it cannot be combined with --from-f32")
     import mimamo_net_amd  # noqa: F401
     from mimamo_net_amd import dist as mdist
     _, env_w, _ = mdist.env_world()
