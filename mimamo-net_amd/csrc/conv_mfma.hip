@@ -29,6 +29,7 @@
 // outputs are written with the non-temporal hint: the next layer reads them from HBM, not from L2).
 #include "mm_common.h"
 #include <cstdio>
+#include <cstdlib>
 #include "conv.h"
 
 namespace mm {
@@ -93,7 +94,7 @@ conv_mfma_kernel(const ConvParams p) {
     const float* __restrict__ w_b = p.w + (int64_t)bz * p.w_bstride;
     float* __restrict__ out_b = p.out + (int64_t)bz * p.out_bstride;
     const int tile_m = logical / p.tiles_n, tile_n = logical - tile_m * p.tiles_n;
-    const int m_base = tile_m * BM, n_base = tile_n * BN;
+    const int m_base = p.m_off + tile_m * BM, n_base = tile_n * BN;
 
     // ---- operand fetch through buffer descriptors: the hardware range check returns 0 for any offset
     //      >= num_records, which gives zero padding (image border taps, K tail, row/channel tails) without
@@ -425,17 +426,41 @@ conv_mfma_kernel(const ConvParams p) {
     }
 }
 
+// workgroups of an instantiation that fit one CU (registers, LDS), as the runtime computes it
+template <int BM, int BN, int WGM, int WGN, int KMODE>
+static int occ_km() {
+    static int occ = 0;
+    if (!occ) {
+        int n = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, conv_mfma_kernel<BM, BN, WGM, WGN, KMODE, false>, WGM * WGN * 64, 0) != hipSuccess || n < 1)
+            n = 1;
+        occ = n;
+    }
+    return occ;
+}
+
+static int num_cus() {
+    static int n = 0;
+    if (!n) {
+        int dev = 0, v = 0;
+        (void)hipGetDevice(&dev);
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v < 1) v = 256;
+        n = v;
+    }
+    return n;
+}
+
 template <int BM, int BN, int WGM, int WGN, int KMODE, bool ABL = false>
 static int launch_km(ConvParams p, hipStream_t stream) {
-    p.tiles_m = (p.M + BM - 1) / BM;
+    p.tiles_m = (p.M - p.m_off + BM - 1) / BM;
     p.tiles_n = (p.Cout + BN - 1) / BN;
     if (p.batch < 1) p.batch = 1;
     const int64_t blocks = (int64_t)p.tiles_m * p.tiles_n * p.batch;
     if (blocks <= 0 || blocks > 0x7fffffff) return MM_ERR_INVALID_ARG;
     if (prof_enabled()) {
         char tag[64];
-        snprintf(tag, sizeof(tag), "M=%d K=%d N=%d k%d s%d t%dx%d b%d", p.M, p.K, p.Cout, p.kh, p.stride, BM, BN, p.batch);
-        prof_before(0, 2.0 * (double)p.M * (double)(p.kh * p.kw * p.Cin_real) * (double)p.Cout * (double)p.batch, stream, tag);
+        snprintf(tag, sizeof(tag), "M=%d K=%d N=%d k%d s%d t%dx%d b%d", p.M - p.m_off, p.K, p.Cout, p.kh, p.stride, BM, BN, p.batch);
+        prof_before(0, 2.0 * (double)(p.M - p.m_off) * (double)(p.kh * p.kw * p.Cin_real) * (double)p.Cout * (double)p.batch, stream, tag);
     }
     hipLaunchKernelGGL((conv_mfma_kernel<BM, BN, WGM, WGN, KMODE, ABL>), dim3((unsigned)blocks), dim3(WGM * WGN * 64), 0, stream, p);
     prof_after(0, stream);
@@ -482,7 +507,8 @@ int conv_forward(const ConvParams& p0, hipStream_t stream) {
         if (span * p.H2 * p.W2 * p.in2_cstride * 4 >= 0x7FFFF000ll) return MM_ERR_INVALID_ARG;
     }
     p.M = p.B * p.Ho * p.Wo;
-    if (p.M <= 0) return MM_OK;
+    if (p.m_end > 0 && p.m_end < p.M) p.M = p.m_end;            // (the bulk launch of a tail split ends early)
+    if (p.M <= p.m_off) return MM_OK;
     if (p.Cin_real <= 0) p.Cin_real = p.Cin;
     // Tile choice.  Wave tile 64x64 (2x2 MFMA sub-tiles, 4 accumulators) is the efficient shape: 128x128
     // blocks (2x2 waves) when Cout > 64, 256x64 blocks (4x1 waves) for the 64-channel layers; smaller tiles
@@ -507,6 +533,38 @@ int conv_forward(const ConvParams& p0, hipStream_t stream) {
         if (p.Cout > 64 && m128 * n128 * nb >= 512) cfg = 1;
         else if (m128 * n64 * nb >= 512) cfg = 2;
         else cfg = 3;
+    }
+    // Tail split (round 3).  A GEMM whose tile count is not a multiple of the resident workgroup slots ends with a partial round:
+    // 3 136 tiles of 128x256 on 512 slots = 6.125 rounds, the seventh running 64 workgroups on a chip that holds 512 (12.5 % of the
+    // 1024 -> 256 layers' time; 23 % of the 2048 -> 512 layers').  The rows of the full rounds stay on the big tile; the rows of the
+    // partial round go to a second launch on a finer tile that spreads them over the whole chip.  Same kernel body, same k order:
+    // every output element is the same sum in the same order (bit-identical to the unsplit launch).  Only when the partial round is
+    // less than 30 % full: measured per layer (2 048 frames, one stream) 1024 -> 256 x5 8.11 -> 7.80 ms, 2048 -> 512 x2 3.37 -> 3.01,
+    // 1536 -> 2048 4.63 -> 4.56; a half-full last round (256 -> 1024, 768 -> 1024, 512 -> 128) is cheaper left on the big tile.  And only
+    // for launches of three or more full rounds: the lanes of the default pipeline run a third of the batch each (two rounds of the
+    // 1024 -> 256 layer), and there another lane's kernels already fill a tail -- splitting those cost 0.6 ms per step.
+    static const int split_on = getenv("MM_TAIL_SPLIT") ? atoi(getenv("MM_TAIL_SPLIT")) : 1;   // measurement knob
+    if (split_on && p.force_tile == 0 && (cfg == 5 || cfg == 1) && p.kh == 1 && p.kw == 1 && p.pad == 0 && p.batch <= 1 && p.m_off == 0) {
+        const int bm = 128, bn = cfg == 5 ? 256 : 128;
+        const int occ = cfg == 5 ? (p.in2 ? occ_km<128, 256, 2, 4, 6>() : occ_km<128, 256, 2, 4, 3>())
+                                 : (p.in2 ? occ_km<128, 128, 2, 2, 6>() : occ_km<128, 128, 2, 2, 3>());
+        const int64_t slots = (int64_t)occ * num_cus();
+        const int64_t tn = (p.Cout + bn - 1) / bn, tm = (p.M + bm - 1) / bm;
+        const int64_t full = tm * tn / slots;                      // whole rounds
+        const int64_t rest = tm * tn - full * slots;               // workgroups of the partial round
+        const int64_t tm_bulk = full * slots / tn;                 // m-tiles the whole rounds cover
+        if (p.m_end == 0 && full >= 3 && rest > 0 && rest * 100 <= slots * 30 && tm_bulk < tm && tm_bulk * bm < p.M) {
+            ConvParams pb = p, pr = p;
+            pb.m_end = (int)(tm_bulk * bm);
+            pb.force_tile = cfg;
+            pr.m_off = pb.m_end;
+            const int64_t R = p.M - pb.m_end;
+            // remainder tile: 128x128 when that still gives the chip enough workgroups, else 64x64
+            const int64_t t128 = ((R + 127) / 128) * ((p.Cout + 127) / 128);
+            pr.force_tile = t128 * 2 >= (int64_t)num_cus() * 3 ? 1 : 3;
+            const int rc = conv_forward(pb, stream);
+            return rc != MM_OK ? rc : conv_forward(pr, stream);
+        }
     }
     switch (cfg) {
         case 1: return launch_cfg<128, 128, 2, 2>(p, stream);
