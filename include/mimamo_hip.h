@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define MM_VERSION 100 /* 0.1.0 */
+#define MM_VERSION 103 /* 0.1.3: round 3 adds mm_phase_diff_planes, mm_head_create_cfg, mm_head_blob_floats_cfg */
 
 typedef enum mm_status {
     MM_OK = 0,

@@ -26,7 +26,7 @@ def test_exports_match_header(L):
     assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
     for name in declared:
         assert hasattr(L, name), name
-    assert L.mm_version() == 100
+    assert L.mm_version() == 103
     assert b"too small" in L.mm_status_string(-2)
 
 
