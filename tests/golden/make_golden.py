@@ -339,6 +339,38 @@ def g8_scfpyr_full(ref):
     np.savez_compressed(os.path.join(HERE, "scfpyr_full.npz"), **out)
 
 
+def g12_sampler_keywords(ref):
+    """Snippet_Sampler with other length / stride / num_phase keywords (api/sampler/snippet_sampler.py:107-152): overlapping
+    snippets (stride < length), gaps (stride > length), a short video, one- and two-frame videos, an even number of frames in
+    the window -- ranges and clamped window ids of the real class."""
+    from PIL import Image
+    out = {}
+    cases = [(100, 32, 16, 12), (309, 64, 32, 12), (50, 64, 64, 12), (65, 64, 64, 12), (1, 64, 64, 12), (2, 64, 64, 12), (13, 8, 5, 12),
+             (40, 16, 24, 6), (30, 10, 10, 7)]
+    for n, length, stride, num_phase in cases:
+        with tempfile.TemporaryDirectory() as d:
+            feat = os.path.join(d, "feat")
+            root = os.path.join(d, "v_opface")
+            os.makedirs(feat)
+            os.makedirs(os.path.join(root, "v_aligned"))
+            for i in range(1, n + 1):
+                np.save(os.path.join(feat, "%05d.npy" % i), np.full((4,), i, dtype=np.float32))
+                Image.fromarray(np.full((8, 8, 3), (i - 1) % 251, dtype=np.uint8), "RGB").save(
+                    os.path.join(root, "v_aligned", "frame_det_00_%06d.bmp" % i))
+            ds = ref.Snippet_Sampler("v", root, feat, annot_dir=None, label_name="valence_arousal", test_mode=True,
+                                     num_phase=num_phase, phase_size=8, length=length, stride=stride)
+            tag = "%d_%d_%d_%d" % (n, length, stride, num_phase)
+            out["ranges_" + tag] = np.array(ds.seq_ranges)
+            ids = []
+            for k in range(len(ds)):
+                ph = ds[k][0]
+                ids.append(np.rint(ph[:, :, 0, 0].numpy() * 255).astype(np.int64))
+            out["ids_" + tag] = np.stack(ids)
+    out["cases"] = np.array(cases)
+    np.savez_compressed(os.path.join(HERE, "sampler_keywords.npz"), **out)
+    print("G12", {k: v.shape for k, v in out.items() if k.startswith("ranges")})
+
+
 def nondefault_windows(T=4, P=7):
     """[1,T,P,48,48]: T consecutive 7-frame windows of one textured clip (num_phase = 6)."""
     clip = synthetic.textured_gray(T + P - 1, 48, seed=61)
@@ -384,6 +416,9 @@ if __name__ == "__main__":
         if sys.argv[1:]:
             sys.exit(0)
     ref = ref_shim.load()
+    if sys.argv[1:] == ["g12"]:
+        g12_sampler_keywords(ref)
+        sys.exit(0)
     if sys.argv[1:] == ["g11"]:
         g11_nondefault(ref)
         sys.exit(0)
@@ -406,4 +441,5 @@ if __name__ == "__main__":
     g9_phase_generic(ref)
     g10_train_phase(ref)
     g11_nondefault(ref)
+    g12_sampler_keywords(ref)
     os.system("ls -la %s" % HERE)

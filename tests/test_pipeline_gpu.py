@@ -47,6 +47,22 @@ def test_multi_snippet_video_and_short_video(tester, oracle):
         assert err < OUT_ATOL, (name, err)
 
 
+def test_overlapping_snippets_and_tiny_videos(oracle):
+    """Tester(length=32, stride=16): overlapping snippets -- GRU seq_len 6 for a 100-frame video, later snippets overwrite the frames
+    they share with earlier ones (api/tester.py:113-116) -- and videos of one and two frames (every window clamped to the video:
+    exactly zero phase differences), against the oracle driven with the same keywords."""
+    from mimamo_net_amd.tester import Tester
+    head_sd, resnet_sd = weights.make_two_stream_state_dict(seed=0), weights.make_resnet50_state_dict(seed=0)
+    t = Tester(model_path=None, batch_size=64, head_state_dict=head_sd, resnet_state_dict=resnet_sd, device="cuda:0", length=32, stride=16)
+    clips = [synthetic.make_clip_u8(90, 100), synthetic.make_clip_u8(91, 1), synthetic.make_clip_u8(92, 2)]
+    res = t.test_frames(clips, names=["a", "one", "two"])
+    for name, clip in zip(("a", "one", "two"), clips):
+        want = _oracle_video(oracle, clip, length=32, stride=16)
+        err = np.abs(res[name].values - want).max()
+        print("length 32 / stride 16, %d frames: %.2e" % (len(clip), err))
+        assert res[name].shape == (len(clip), 2) and err < OUT_ATOL, (name, err)
+
+
 def test_independent_clip_batching_is_exact(tester):
     """Batching single-snippet clips into one GRU call (seq_len 1) gives the same bits as one call per clip."""
     clips = [synthetic.make_clip_u8(50 + i, 64) for i in range(3)]
