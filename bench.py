@@ -181,6 +181,11 @@ class HipCompute(object):
         self.resnet_sd = weights.make_resnet50_state_dict(seed=0)
         self.hot = HotPath(self.head_sd, self.resnet_sd, device)
         self.hot.resnet.set_winograd(0 if args.no_winograd else args.winograd)
+        if getattr(args, "lane_cus", ""):
+            from mimamo_net_amd.stream import parse_partitions
+            parts = parse_partitions(args.lane_cus)
+            self.hot.set_lane_partitions(parts)
+            args.lanes = len(parts)
         self.pool = {}          # clip content id -> row in the device-resident pool
         self.frames_u8 = None   # [P*64,112,112,3] uint8
         self.pre = None         # (gray, rgb) of the pool for --from-f32
@@ -235,6 +240,8 @@ class HipCompute(object):
         from mimamo_net_amd.stream import FrameStream
         rows = len(content_ids) * FRAMES_PER_CLIP
         if self._fs is None or self._fs.slots[0].shape[0] < rows:
+            if self._fs is not None:
+                self._fs.close()
             self._fs = FrameStream(self.device, max(rows, self.args.clips * FRAMES_PER_CLIP))
             self._fs_next = 0
         fs = self._fs
@@ -258,7 +265,7 @@ class HipCompute(object):
 
     def _forward(self, ins, n_clips, lanes, u8):
         lengths = [FRAMES_PER_CLIP] * n_clips
-        if lanes > 1:
+        if lanes > 1 or getattr(self.hot, "_lane_partitions", None):    # a single partitioned lane still runs on ITS stream
             return self.hot.forward_lanes(ins, lengths, lanes, independent_clips=True, from_u8=u8)
         plan = self.hot.plan(lengths) if getattr(self, "_plan_n", None) != len(lengths) else self._plan
         self._plan, self._plan_n = plan, len(lengths)
@@ -322,6 +329,9 @@ def parse_args(argv=None):
     ap.add_argument("--no-winograd", action="store_true", help="run every 3x3 layer in the direct implicit-GEMM form")
     ap.add_argument("--winograd", type=int, default=1, help="1 = default (F(4x4,3x3); conv2_x..conv4_x with the output transform fused into the position GEMMs), 2 = F(2x2,3x3), 4 = F(4x4,3x3) as three kernels everywhere, 5 = fused everywhere")
     ap.add_argument("--lanes", type=int, default=3, help="HIP streams the clips of a step are spread over (1 = single stream)")
+    ap.add_argument("--lane-cus", default=os.environ.get("MM_LANE_CUS", ""),
+                    help="measurement: confine lane i to a CU subset, e.g. '0-127/128-255' (two half-chip lanes); implies --lanes = "
+                         "number of subsets.  Default: ordinary streams")
     ap.add_argument("--from-f32", action="store_true",
                     help="start every step from host-preprocessed fp32 tensors (gray 48x48, RGB 224x224) instead of the "
                          "raw uint8 boundary")

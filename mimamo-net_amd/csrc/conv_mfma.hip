@@ -28,6 +28,7 @@
 // bias/residual/output move as 16-byte accesses, 256 bytes per row (wave-private staging, no workgroup barrier;
 // outputs are written with the non-temporal hint: the next layer reads them from HBM, not from L2).
 #include "mm_common.h"
+#include <atomic>
 #include <cstdio>
 #include <cstdlib>
 #include "conv.h"
@@ -41,7 +42,9 @@ constexpr int CLD = 16;   // LDS row = one 16-float chunk; the four 16-byte slot
 
 // ABL: measurement-only instantiation whose loop stages can be switched off at run time (p.ablate bits:
 // 1 no loads + no tap math, 128 no loads, 256 no tap math, 4 no barrier, 8 no fragment reads, 32/64 wave-priority
-// experiments) to attribute time; its results are wrong by construction.  Reached only through tile >= 16.
+// experiments) to attribute time; its results are wrong by construction.  Compiled only with -DMM_MEASURE (the profiling
+// scripts under tools/ build that library; __graft_entry__.build() never does) and reached there through tile >= 16; the
+// default library has no such instantiation and answers tile > 5 with MM_ERR_INVALID_ARG.
 // KMODE selects the tap iteration at compile time (straight-line VALU in the hot loop):
 //   0  k = (r,s,c), any Cin % 4 == 0 (stem: Cin = 4)      2  k = (r,s,c), Cin >= 16 (one wrap per chunk at most)
 //   1  slice-major k = (c/16, r, s, c%16), Cin % 16 == 0    3  1x1 kernel, pad 0: no taps, no border
@@ -426,28 +429,41 @@ conv_mfma_kernel(const ConvParams p) {
     }
 }
 
-// workgroups of an instantiation that fit one CU (registers, LDS), as the runtime computes it
+// Per-device caches (relaxed atomics: a race only repeats the query, every thread stores the same value).
+constexpr int kMaxDev = 64;
+static int cur_dev_slot() {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    return dev >= 0 && dev < kMaxDev ? dev : -1;
+}
+
+// workgroups of an instantiation that fit one CU (registers, LDS), as the runtime computes it for the current device
 template <int BM, int BN, int WGM, int WGN, int KMODE>
 static int occ_km() {
-    static int occ = 0;
-    if (!occ) {
+    static std::atomic<int> occ[kMaxDev];
+    const int d = cur_dev_slot();
+    int v = d >= 0 ? occ[d].load(std::memory_order_relaxed) : 0;
+    if (!v) {
         int n = 0;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, conv_mfma_kernel<BM, BN, WGM, WGN, KMODE, false>, WGM * WGN * 64, 0) != hipSuccess || n < 1)
             n = 1;
-        occ = n;
+        v = n;
+        if (d >= 0) occ[d].store(v, std::memory_order_relaxed);
     }
-    return occ;
+    return v;
 }
 
 static int num_cus() {
-    static int n = 0;
-    if (!n) {
-        int dev = 0, v = 0;
+    static std::atomic<int> cus[kMaxDev];
+    const int d = cur_dev_slot();
+    int v = d >= 0 ? cus[d].load(std::memory_order_relaxed) : 0;
+    if (!v) {
+        int dev = 0;
         (void)hipGetDevice(&dev);
         if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v < 1) v = 256;
-        n = v;
+        if (d >= 0) cus[d].store(v, std::memory_order_relaxed);
     }
-    return n;
+    return v;
 }
 
 template <int BM, int BN, int WGM, int WGN, int KMODE, bool ABL = false>
@@ -516,10 +532,14 @@ int conv_forward(const ConvParams& p0, hipStream_t stream) {
     const int64_t m128 = (p.M + 127) / 128, m256 = (p.M + 255) / 256;
     const int64_t n128 = (p.Cout + 127) / 128, n64 = (p.Cout + 63) / 64;
     int cfg = p.force_tile;
+#ifdef MM_MEASURE
     if (cfg >= 16) {  // measurement-only: 128x128 with experiment bits (cfg - 16)
         p.ablate = cfg - 16;
         return launch_km<128, 128, 2, 2, 1, true>(p, stream);  // slice-major 3x3 shapes only
     }
+#else
+    if (cfg > 5) return MM_ERR_INVALID_ARG;
+#endif
     if (cfg == 0) {
         // 1x1 / GEMM shapes whose N is a multiple of 256 (ResNet increase / projection layers, the Winograd GEMMs of
         // conv4_x and conv5_x): one 128x256 workgroup of eight waves covers the full N per 256 columns, so every

@@ -346,8 +346,13 @@ int mm_conv2d_nhwc(const float* in, const float* w, const float* bias, const flo
                    int relu, int tile, int korder, void* stream) {
     using namespace mm;
     if (!in || !w || !out || B < 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || kh <= 0 || kw <= 0 || stride <= 0 ||
-        pad < 0 || tile < 0 || tile > 2047)
+        pad < 0 || tile < 0)
         return MM_ERR_INVALID_ARG;
+#ifdef MM_MEASURE
+    if (tile > 2047) return MM_ERR_INVALID_ARG;     // tile >= 16: the ablation instantiation of conv_mfma.hip (measurement builds only)
+#else
+    if (tile > 5) return MM_ERR_INVALID_ARG;        // the documented range; the default library has no measurement modes
+#endif
     if ((post_scale == nullptr) != (post_shift == nullptr)) return MM_ERR_INVALID_ARG;
     ConvParams p;
     std::memset(&p, 0, sizeof(p));

@@ -408,11 +408,17 @@ int64_t phase_frames_floats(int W, int64_t n) {
 // frames [n][48][48] -> frame planes of both levels (the whole per-unique-frame part of the fused phase stage)
 int launch_pyramid_frames(const mm_pyramid* h, const float* frames, int64_t n, float* f1, float* f2, hipStream_t stream) {
     if (n <= 0) return MM_OK;
+    // MM_PF_LDS_PAD / MM_PF_ABLATE (attribution of the kernel's time to its parts; results wrong by construction) exist only in a
+    // library built with -DMM_MEASURE (tools/ scripts); the default build ignores the variables and always runs the full kernel
+#ifdef MM_MEASURE
     static const int lds_pad = getenv("MM_PF_LDS_PAD") ? atoi(getenv("MM_PF_LDS_PAD")) : 0;   // measurement knob: force one workgroup per CU
+    static const int ablate = getenv("MM_PF_ABLATE") ? atoi(getenv("MM_PF_ABLATE")) : 0;     // measurement knob: skip parts of the kernel
+#else
+    constexpr int lds_pad = 0, ablate = 0;
+#endif
     const int lds_bytes = pf::L_TOTAL * 4 + lds_pad;
     MM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(pf::pyramid_frame_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                lds_bytes));
-    static const int ablate = getenv("MM_PF_ABLATE") ? atoi(getenv("MM_PF_ABLATE")) : 0;     // measurement knob: skip parts of the kernel
     static const int grid_cap = getenv("MM_PF_GRID") ? atoi(getenv("MM_PF_GRID")) : 2048;
     int64_t grid = n;
     if (grid > grid_cap) grid = grid_cap;   // 256 CUs x 2 resident workgroups x 4 rounds; the rest grid-strides (tables stay in LDS)

@@ -156,7 +156,11 @@ class HotPath(object):
         key = torch.cuda.current_stream().cuda_stream
         fs = self._feeders.get(key)
         if fs is None or fs.slots[0].shape[0] != chunk:
+            if fs is not None:
+                fs.close()
             if len(self._feeders) > 8:
+                for old in self._feeders.values():
+                    old.close()
                 self._feeders.clear()
             fs = self._feeders[key] = FrameStream(self.device, chunk)
         gray = torch.empty((N, self._pre.phase_size, self._pre.phase_size), dtype=torch.float32, device=self.device)
@@ -234,12 +238,16 @@ class HotPath(object):
         _, plans, frs = cache
         # one persistent pool of side streams: per-stream workspaces (Resnet50_Extractor) are keyed by stream, so new
         # streams for every new (lengths, lanes) combination would strand tens of GB of workspace each
-        pool = getattr(self, "_lane_streams", None)
-        if pool is None:
-            pool = self._lane_streams = []
-        while len(pool) < lanes:
-            pool.append(torch.cuda.Stream(device=self.device))
-        streams = pool[:lanes]
+        parts = getattr(self, "_lane_partitions", None)
+        if parts is not None and len(parts) >= lanes:
+            streams = [p.stream for p in parts[:lanes]]            # CU-partitioned lanes (set_lane_partitions)
+        else:
+            pool = getattr(self, "_lane_streams", None)
+            if pool is None:
+                pool = self._lane_streams = []
+            while len(pool) < lanes:
+                pool.append(torch.cuda.Stream(device=self.device))
+            streams = pool[:lanes]
         cur = torch.cuda.current_stream()
         outs = []
         for plan, (f0, f1), st in zip(plans, frs, streams):
@@ -252,6 +260,17 @@ class HotPath(object):
         for st in streams:
             cur.wait_stream(st)
         return torch.cat(outs, 0)
+
+    def set_lane_partitions(self, cu_lists):
+        """Confine the lanes of forward_lanes to CU subsets: cu_lists[i] = CU indices lane i may use (stream.PartitionStream), or
+        None to go back to ordinary streams.  Measurement lever of round 4: an HBM-bound kernel holds the full
+        bandwidth on half the chip, so two half-chip lanes leave the other half to the other lane's GEMMs."""
+        from .stream import PartitionStream
+        old = getattr(self, "_lane_partitions", None)
+        self._lane_partitions = None if not cu_lists else [PartitionStream(c, self.device) for c in cu_lists]
+        if old:
+            for p in old:
+                p.close()
 
     def assemble(self, out_rows, plan, label_name=('valence', 'arousal')):
         """[rows,2] -> {video index: float64 [n_frames,2]} with the reference's overwrite order."""

@@ -134,6 +134,66 @@ def test_conv_engine_is_deterministic_under_load(pkg, dev, case):
         assert torch.equal(run(x[lo:lo + nb].contiguous()), first[lo:lo + nb])
 
 
+def _count_conv_launches(fn):
+    """Launches of the conv engine inside fn() (the library's measurement hook brackets each one)."""
+    from mimamo_net_amd import _lib
+    L = _lib.lib()
+    ms, work, n = (ctypes.c_double * 4)(), (ctypes.c_double * 4)(), (ctypes.c_int64 * 4)()
+    assert L.mm_profile_begin() == 0
+    fn()
+    assert L.mm_profile_end(ms, work, n) == 0
+    return int(n[0])
+
+
+SPLIT_CASES = [
+    # B, side, Cin, Cout, residual.  M = 200 704 rows = 1 568 tiles of 128x256 on 512 resident workgroups = 3.06 rounds: conv_forward
+    # gives the 1 536 tiles of the full rounds to the 128x256 kernel and rows [196 608, 200 704) to a second launch on 64x64 tiles
+    (1024, 14, 1024, 256, False),    # the conv4_x reduce shape (K = 1024)
+    (64, 56, 64, 256, True),         # the conv2_x increase layer at batch 64, with its residual (what the bench-sized step runs)
+]
+
+
+@pytest.mark.parametrize("case", SPLIT_CASES)
+def test_tail_split_is_bit_identical_to_the_unsplit_launch(pkg, dev, case):
+    """conv_mfma.hip's tail split (tile = 0: bulk rows on the big tile, the partial last round on a finer tile) against the same
+    layer forced onto ONE 128x256 launch (tile = 5 never splits): every output bit equal, and rows on both sides of the split
+    boundary against a float64 evaluation."""
+    from mimamo_net_amd import _lib
+    B, side, Ci, Co, with_res = case
+    M = B * side * side
+    g = torch.Generator(device="cpu").manual_seed(Ci + Co)
+    x = (torch.rand(M, Ci, generator=g) - 0.5).to(dev)
+    w = ((torch.rand(Co, Ci, generator=g) - 0.5) / np.sqrt(Ci)).to(dev)
+    b = (torch.rand(Co, generator=g) - 0.5).to(dev)
+    res = (torch.rand(M, Co, generator=g) - 0.5).to(dev) if with_res else None
+
+    def run(tile):
+        out = torch.full((M, Co), float("nan"), device=dev)
+        rc = _lib.lib().mm_conv2d_nhwc(_lib.ptr(x), _lib.ptr(w), _lib.ptr(b), _lib.ptr(res), None, None, _lib.ptr(out), B, side, side,
+                                       Ci, Ci, 0, Co, Co, 0, Co, 1, 1, 1, 0, 1, tile, 0, _lib.current_stream())
+        assert rc == 0
+        return out
+
+    outs = {}
+    n_auto = _count_conv_launches(lambda: outs.__setitem__(0, run(0)))
+    n_one = _count_conv_launches(lambda: outs.__setitem__(5, run(5)))
+    assert n_one == 1 and n_auto == 2, ("the auto launch was expected to split into bulk + remainder", n_auto, n_one)
+    assert torch.isfinite(outs[0]).all()
+    assert torch.equal(outs[0], outs[5])
+    # rows around the boundary of the bulk launch (1 536 tiles x 128 rows with two 128x256 workgroups resident per CU on 256 CUs),
+    # the first and last rows, and a strided sample, against float64
+    bnd = 1536 * 128
+    rows = sorted(set([0, 1, 127, 128, bnd - 129, bnd - 2, bnd - 1, bnd, bnd + 1, bnd + 63, bnd + 64, bnd + 65, M - 65, M - 64, M - 2, M - 1]
+                      + list(range(5, M, 4099))))
+    idx = torch.tensor(rows, device=dev)
+    ref = x[idx].double().cpu() @ w.double().cpu().t() + b.double().cpu()
+    if with_res:
+        ref = ref + res[idx].double().cpu()
+    ref = torch.relu(ref)
+    err = (outs[0][idx].double().cpu() - ref).abs().max().item()
+    assert err < 2e-5, err
+
+
 @pytest.mark.parametrize("tile", [4, 1])
 def test_conv_engine_at_the_32bit_offset_limit(pkg, dev, tile):
     """The engine addresses a block's rows with 32-bit byte offsets from the block's first image (conv_mfma.hip: the A
@@ -352,6 +412,26 @@ def test_resnet50_full_batch_properties(resnet, dev):
     assert torch.isfinite(a).all() and torch.equal(a, b)
     sub = resnet.get_vec(x[10:14].contiguous())
     assert (sub - a[10:14]).abs().max() / a.abs().max() < 1e-5
+
+
+def test_resnet50_batch64_remainder_rows_vs_oracle(resnet, oracle, dev):
+    """At batch 64 the conv2_x increase layers (M = 200 704, 3.06 rounds) run through conv_forward's tail split: rows from
+    196 608 on -- the end of frame 62 and frame 63 -- come from the remainder launch.  Frames 60-63 (both sides of the boundary)
+    against the oracle, and against the same frames computed as a batch of 4 (no split at that size)."""
+    xs = _images(64, 2)
+    x = torch.from_numpy(xs).to(dev)
+    n = _count_conv_launches(lambda: resnet.get_vec(x))
+    n4 = _count_conv_launches(lambda: resnet.get_vec(x[60:64].contiguous()))
+    assert n > n4, ("expected split launches at batch 64", n, n4)
+    got = resnet.get_vec(x)[60:64].cpu().numpy()
+    want = oracle.resnet50_pool5(weights.make_resnet50_state_dict(seed=0), xs[60:64])
+    scale = np.abs(want).max()
+    mx, mean = np.abs(got - want).max() / scale, np.abs(got - want).mean() / scale
+    print("batch-64 frames 60-63 vs oracle: max rel %.2e mean rel %.2e (conv launches %d vs %d at batch 4)" % (mx, mean, n, n4))
+    assert mx < POOL5_RTOL * 10 and mean < POOL5_RTOL, (mx, mean)
+    assert mx < POOL5_TIGHT_MAX and mean < POOL5_TIGHT_MEAN, ("regression bound", mx, mean)
+    sub = resnet.get_vec(x[60:64].contiguous()).cpu().numpy()
+    assert np.abs(sub - got).max() / scale < 1e-5
 
 
 def test_zero_sized_calls_are_noops(pkg, dev):
