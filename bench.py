@@ -28,6 +28,7 @@ import os
 import sys
 import time
 
+T_PROCESS_START = time.time()
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 # One hardware queue per HIP stream this process uses: the three lane streams, torch's default stream, the copy stream of a
@@ -190,13 +191,34 @@ class HipCompute(object):
         self.frames_u8 = None   # [P*64,112,112,3] uint8
         self.pre = None         # (gray, rgb) of the pool for --from-f32
 
-    def load(self, content_ids):
-        """Synthetic clips (seed 1000 + id) -> HBM, outside the timed region."""
+    def load(self, content_ids, share=None):
+        """Synthetic clips (seed 1000 + id) -> HBM, outside the timed region.
+        share = (rank, world, distinct, collective device) at N > 1: the pool of `distinct` clip contents is generated ONCE across
+        the job -- rank r makes contents [r * per, (r + 1) * per) -- and all-gathered (RCCL, device to device), so every rank holds the
+        whole pool (any clip of the queue can run anywhere) and no content is generated twice."""
         from mimamo_net_amd import synthetic
+        from mimamo_net_amd import stream as mstream
+        if share is not None and share[1] > 1 and not self.args.from_f32:
+            from mimamo_net_amd import dist as mdist
+            rank, world, distinct, coll_dev = share
+            per = (distinct + world - 1) // world
+            mine = [c for c in range(rank * per, (rank + 1) * per)]
+            part = np.zeros((per * FRAMES_PER_CLIP, 112, 112, 3), dtype=np.uint8)
+            for i, c in enumerate(mine):
+                if c < distinct:
+                    part[i * FRAMES_PER_CLIP:(i + 1) * FRAMES_PER_CLIP] = synthetic.make_clip_u8(c, FRAMES_PER_CLIP)
+            allf = mdist.all_gather_bytes(torch.from_numpy(part), world, coll_dev)[:distinct * FRAMES_PER_CLIP]
+            self.pool = {c: c for c in range(distinct)}
+            self.pool_generated_here = len([c for c in mine if c < distinct])
+            self.frames_u8 = allf.to(self.device)
+            self.frames_host = mstream.pin(allf.cpu()) if self.args.stream_input else None
+            self._fs = None
+            self._sel = {}
+            return
         ids = sorted(set(int(c) for c in content_ids))
         self.pool = {c: i for i, c in enumerate(ids)}
+        self.pool_generated_here = len(ids)
         clips = [synthetic.make_clip_u8(c, FRAMES_PER_CLIP) for c in ids]
-        from mimamo_net_amd import stream as mstream
         self.frames_host = mstream.pin(np.concatenate(clips))           # the raw boundary in page-locked host memory
         self.frames_u8 = self.frames_host.to(self.device)
         self._fs = None
@@ -285,7 +307,9 @@ class StubCompute(object):
     def __init__(self, args, device):
         self.device = device
 
-    def load(self, content_ids):
+    pool_generated_here = 0
+
+    def load(self, content_ids, share=None):
         pass
 
     def step(self, content_ids, lanes=None):
@@ -322,6 +346,7 @@ def parse_args(argv=None):
     ap.add_argument("--force-dist", action="store_true",
                     help="testing only: create the process group (RCCL) even with one rank, to exercise the broadcast / "
                          "all-gather path on a single-GPU box")
+    ap.add_argument("--no-cpu-bind", action="store_true", help="N > 1: do not pin the rank's host threads to its GPU's NUMA node")
     ap.add_argument("--no-step-gather", action="store_true",
                     help="diagnosis only: keep the process group but skip the per-step all-gather of the result rows")
     ap.add_argument("--stub-compute", action="store_true", help="testing only: no GPU work (launcher / work-queue plumbing)")
@@ -374,7 +399,13 @@ def run_rank(args):
     backend = args.backend or ("nccl" if gpu else "gloo")
     _, env_w, env_local = mdist.env_world()
     dev_index = 0 if args.same_device else env_local
+    t_init = time.perf_counter()
     rank, world, local_rank = mdist.init(backend, device_index=dev_index if gpu else None, force=args.force_dist)
+    init_s = time.perf_counter() - t_init
+    # host side of a rank: its threads stay on the CPUs next to its GPU (NUMA node from sysfs; an even slice of the allowed CPUs
+    # when the platform does not say).  N = 1 stays unbound: rank 0 alone runs the cpu_baseline on the whole host.
+    cpu_bind = mdist.bind_rank_cpus(local_rank, world, ([0] * world if args.same_device else list(range(world))) if gpu else None) \
+        if world > 1 and not args.no_cpu_bind else {"numa_node": None, "cpus": len(os.sched_getaffinity(0)), "first_cpu": -1, "bound": False}
     if gpu:
         torch.cuda.set_device(dev_index)
         device = torch.device("cuda", dev_index)
@@ -405,10 +436,13 @@ def run_rank(args):
         warm, timed = seq[:args.warmup], seq[args.warmup:]
     content = lambda ids: [c % distinct for c in ids]                         # noqa: E731
 
+    t_w = time.perf_counter()
     comp = (StubCompute if args.stub_compute else HipCompute)(args, device)
+    weights_s = time.perf_counter() - t_w            # weights generated / folded / uploaded (each rank: replicated, 105 MB)
     t_l = time.perf_counter()
-    comp.load({c % distinct for s in warm + timed for c in s})
+    comp.load({c % distinct for s in warm + timed for c in s}, share=(rank, world, distinct, coll_dev))
     load_s = time.perf_counter() - t_l
+    startup_s = time.time() - T_PROCESS_START        # interpreter start -> ready to run the first warm-up step
 
     # The [frames,2] results of a step are all-gathered (8 B/frame, the only collective besides the queue broadcast).  It
     # is issued asynchronously on RCCL's stream and only waited for one step later, so a rank never stalls on a slower
@@ -506,9 +540,15 @@ def run_rank(args):
         # one row per rank, gathered with the collective the results use: enough to tell a slow rank (ms_per_step_local), a
         # rank held up by its peers (ms_per_step >> local) or a slow communicator set-up (queue_broadcast_ms) apart
         rows = mdist.all_gather_floats([rank, dt_local / max(n_steps, 1) * 1e3, dt_own / max(n_steps, 1) * 1e3, frames_rank,
-                                        bcast_ms, load_s, dev_index if gpu else -1], coll_dev)
+                                        bcast_ms, load_s, dev_index if gpu else -1, startup_s, init_s, weights_s,
+                                        cpu_bind["cpus"], cpu_bind["first_cpu"],
+                                        -1 if cpu_bind["numa_node"] is None else cpu_bind["numa_node"], comp.pool_generated_here],
+                                       coll_dev)
         result["per_rank"] = [{"rank": int(r[0]), "ms_per_step_local": r[1], "ms_per_step": r[2], "frames": int(r[3]),
-                               "queue_broadcast_ms": r[4], "input_load_s": r[5], "device": int(r[6])} for r in rows]
+                               "queue_broadcast_ms": r[4], "input_load_s": r[5], "device": int(r[6]),
+                               "startup_s": r[7], "process_group_init_s": r[8], "weights_s": r[9],
+                               "cpus": int(r[10]), "first_cpu": int(r[11]), "numa_node": None if r[12] < 0 else int(r[12]),
+                               "clip_contents_generated": int(r[13])} for r in rows]
         result["config"]["work_queue"]["broadcast_ms_rank0"] = bcast_ms if rank == 0 else None
     if args.stub_compute:
         if rank == 0:

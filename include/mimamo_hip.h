@@ -217,7 +217,7 @@ int mm_head_create_mlp(mm_head_t** out, const float* host_blob, int64_t n_floats
 /* Two_Stream_RNN(mlp_hidden_units, num_phase=...) (api/mimamo_net.py:97-112): PhaseNet takes 2 * num_phase channels per level
  * (phase_0 [bs,T,2*num_phase,48,48], phase_1 [bs,T,2*num_phase,24,24]); the state_dict's conv_net.0.0 / conv_net.1.0 weights have
  * 2*num_phase / 64 + 2*num_phase input channels.  num_phase must be even and <= 32 (16-byte channel groups), otherwise
- * MM_ERR_UNSUPPORTED.  mm_head_create_mlp == num_phase 12 (api/tester.py:28). */
+ * MM_ERR_UNSUPPORTED (from both functions).  mm_head_create_mlp == num_phase 12 (api/tester.py:28). */
 int64_t mm_head_blob_floats_cfg(int n_units, const int* units, int num_phase);
 int mm_head_create_cfg(mm_head_t** out, const float* host_blob, int64_t n_floats, int n_units, const int* units, int num_phase);
 int mm_head_destroy(mm_head_t* h);

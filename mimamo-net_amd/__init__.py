@@ -14,6 +14,8 @@ _LAZY = {
     "Resnet50_Extractor": ".resnet50_extractor",
     "Two_Stream_RNN": ".mimamo_net",
     "Tester": ".tester",
+    "Snippet_Sampler": ".sampler",
+    "Image_Sampler": ".sampler",
 }
 
 

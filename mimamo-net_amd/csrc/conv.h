@@ -24,8 +24,8 @@ struct ConvParams {
     int Cin_real;    // un-padded input channels (FLOP accounting only; 0 = Cin)
     int batch;       // >1: `batch` independent problems of this shape in one launch (0/1 = single)
     int64_t in_bstride, w_bstride, out_bstride;   // element strides between the problems of a batch
-    int M, tiles_m, tiles_n;  // filled by conv_forward (M: exclusive end row of this launch)
-    int m_end;       // exclusive end row of this launch (0 = all B * Ho * Wo rows)
+    int M, tiles_m, tiles_n;  // filled by conv_forward (M = exclusive end row of the launch: B * Ho * Wo, or m_end when that is smaller)
+    int m_end;       // caller-side cap on the rows of this launch: rows [m_off, m_end) are computed (0 = up to B * Ho * Wo)
     int m_off;       // first output row of this launch (conv_forward's tail split: bulk rows on the big tile, the last partial
                      // round of workgroups as a second launch on a finer tile); 0 from callers
     // second K source of a 1x1 layer (null = none): out = W[:, :Cin] * in(pixel) + W[:, Cin:] * in2(pixel * stride2), i.e. a residual

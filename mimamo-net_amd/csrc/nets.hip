@@ -565,8 +565,9 @@ int mm_head_create_mlp(mm_head_t** out, const float* blob, int64_t n_floats, int
 }
 
 int64_t mm_head_blob_floats_cfg(int n_units, const int* units, int num_phase) {
-    return mm::mlp_units_ok(n_units, units) && mm::phase_channels_ok(2 * num_phase) ? mm::head_blob_floats(n_units, units, 2 * num_phase)
-                                                                                      : (int64_t)MM_ERR_INVALID_ARG;
+    if (!mm::mlp_units_ok(n_units, units) || num_phase < 1) return (int64_t)MM_ERR_INVALID_ARG;
+    if (!mm::phase_channels_ok(2 * num_phase)) return (int64_t)MM_ERR_UNSUPPORTED;   // as mm_head_create_cfg: odd or > 32 differences
+    return mm::head_blob_floats(n_units, units, 2 * num_phase);
 }
 
 int mm_head_create_cfg(mm_head_t** out, const float* blob, int64_t n_floats, int n_units, const int* units, int num_phase) {
@@ -595,11 +596,12 @@ int mm_head_create_cfg(mm_head_t** out, const float* blob, int64_t n_floats, int
         if (rc == MM_OK) rc = make_layer(h->arena, L, w, b, o, i, 1, 1, 0, 1, &bn, nullptr, eps);
     };
     // Conv3x3(+bias) -> BN -> ReLU  (PhaseNet._make_conv_layer, :68-78)
-    auto conv_bn_relu = [&](Layer& L, int o, int i, int stride) {
+    auto conv_bn_relu = [&](Layer& L, int o, int i, int stride, bool wino) {
         const float* w = take((int64_t)o * i * 9); const float* b = take(o); BN bn = take_bn(o);
-        // Winograd-domain weights for the fused F(4x4,3x3) kernel (stride 1, K a multiple of 64): 88 -> 128 at 24x24, 128 -> 256 at 12x12
-        // (the 88-channel concat layer gets 40 zero columns)
-        if (rc == MM_OK) rc = make_layer(h->arena, L, w, b, o, i, 3, stride, 1, 1, &bn, nullptr, eps, stride == 1 && i >= 64, false, 64);
+        // Winograd-domain weights for the fused F(4x4,3x3) kernel (stride 1, K a multiple of 64) only for the two layers
+        // mm_head_forward runs through it: (64 + pc) -> 128 at 24x24 (the concat layer gets zero columns up to 128) and 128 -> 256
+        // at 12x12
+        if (rc == MM_OK) rc = make_layer(h->arena, L, w, b, o, i, 3, stride, 1, 1, &bn, nullptr, eps, wino, false, 64);
     };
     // Linear -> ReLU -> BN  (PhaseNet.fc :54-62, transform :115-117)
     auto lin_relu_bn = [&](Layer& L, int o, int i) {
@@ -619,8 +621,8 @@ int mm_head_create_cfg(mm_head_t** out, const float* blob, int64_t n_floats, int
     }
     const int ch[3][2] = {{pc, 64}, {64 + pc, 128}, {128, 256}};
     for (int i = 0; i < 3; ++i) {
-        conv_bn_relu(h->conv[2 * i], ch[i][1], ch[i][0], 1);
-        conv_bn_relu(h->conv[2 * i + 1], ch[i][1], ch[i][1], 2);
+        conv_bn_relu(h->conv[2 * i], ch[i][1], ch[i][0], 1, i >= 1);      // conv[2], conv[4]
+        conv_bn_relu(h->conv[2 * i + 1], ch[i][1], ch[i][1], 2, false);
     }
     lin_relu_bn(h->fc1, 256, 256);
     lin_relu_bn(h->fc2, 256, 256);

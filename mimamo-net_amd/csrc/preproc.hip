@@ -288,6 +288,7 @@ struct mm_preproc {
     float mean[3];
     mm::ResampleTable lan, bil;
     int *d_lan_bounds = nullptr, *d_lan_kk = nullptr, *d_bil_bounds = nullptr, *d_bil_kk = nullptr;
+    int rgb3_max_in = 0;   // most input rows a 16-row block of preproc_rgb3_kernel touches, from the bounds table itself
     int device = 0;
 };
 
@@ -330,6 +331,17 @@ int mm_preproc_create(mm_preproc_t** out, int in_size, int gray_size, int resize
     if (rc == MM_OK) rc = up(h->lan.kk, &h->d_lan_kk);
     if (rc == MM_OK) rc = up(h->bil.bounds, &h->d_bil_bounds);
     if (rc == MM_OK) rc = up(h->bil.kk, &h->d_bil_kk);
+    if (rc == MM_OK) {
+        // exact LDS need of preproc_rgb3_kernel: the kernel stages n_in = bounds[last].min + bounds[last].count - bounds[first].min
+        // input rows per block of RGB_ROWS cropped output rows; take the maximum over the blocks the launch will have
+        const int off = (int)rintf((resize - crop) / 2.0f);
+        for (int row0 = 0; row0 < crop; row0 += mm::RGB_ROWS) {
+            const int rows = crop - row0 < mm::RGB_ROWS ? crop - row0 : mm::RGB_ROWS;
+            const int yf = row0 + off, yl = row0 + rows - 1 + off;
+            const int n_in = h->bil.bounds[yl * 2] + h->bil.bounds[yl * 2 + 1] - h->bil.bounds[yf * 2];
+            if (n_in > h->rgb3_max_in) h->rgb3_max_in = n_in;
+        }
+    }
     if (rc != MM_OK) {
         mm_preproc_destroy(h);
         return rc;
@@ -362,9 +374,11 @@ int mm_preproc_forward(mm_preproc_t* h, const uint8_t* frames, int64_t n, float*
         MM_LAUNCH_CHECK();
     }
     if (rgb_out && rgb_nchw == 2) {
-        // rows of the block after the horizontal pass: at most RGB_MAX_IN input rows x crop columns x 3 bytes of LDS
-        const int max_in = (int)((double)mm::RGB_ROWS * h->in_size / h->resize) + 4;
-        if (max_in > mm::RGB_MAX_IN || h->bil.ksize > 4) return MM_ERR_UNSUPPORTED;   // (a down-scaling resize: not the reference's 112 -> 256)
+        // rows of the block after the horizontal pass: rgb3_max_in (exact, from the bounds table at create) input rows x crop
+        // columns x 3 bytes of LDS; the kernel's tap arrays hold four vertical taps
+        const int max_in = h->rgb3_max_in;
+        if (max_in <= 0 || max_in > mm::RGB_MAX_IN || h->bil.ksize > 4 || (int64_t)max_in * h->crop * 3 > 60 * 1024)
+            return MM_ERR_UNSUPPORTED;   // (a down-scaling resize: not the reference's 112 -> 256)
         dim3 grid((unsigned)n, (unsigned)((h->crop + mm::RGB_ROWS - 1) / mm::RGB_ROWS));
         hipLaunchKernelGGL(mm::preproc_rgb3_kernel, grid, dim3(256), max_in * h->crop * 3, s, frames, h->in_size, h->resize, h->crop,
                            h->bil.ksize, h->d_bil_bounds, h->d_bil_kk, h->mean[0], h->mean[1], h->mean[2], rgb_out);

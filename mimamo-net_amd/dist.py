@@ -50,6 +50,83 @@ def init(backend=None, device_index=None, force=False):
     return rank, world, local_rank
 
 
+def _parse_cpulist(text):
+    cpus = []
+    for part in text.strip().split(","):
+        if not part:
+            continue
+        a, _, b = part.partition("-")
+        cpus += list(range(int(a), int(b or a) + 1))
+    return cpus
+
+
+def gpu_numa_cpus(device_index):
+    """(numa node, CPUs local to it) of GPU `device_index` from sysfs (/sys/bus/pci/devices/<bdf>/{numa_node,local_cpulist}),
+    or (None, []) when the platform does not say (no GPU, no sysfs entry, numa_node == -1)."""
+    try:
+        pr = torch.cuda.get_device_properties(device_index)
+        bdf = "%04x:%02x:%02x.0" % (pr.pci_domain_id, pr.pci_bus_id, pr.pci_device_id)
+        base = "/sys/bus/pci/devices/" + bdf
+        with open(base + "/numa_node") as f:
+            node = int(f.read().strip())
+        with open(base + "/local_cpulist") as f:
+            cpus = _parse_cpulist(f.read())
+        return (node if node >= 0 else None), (cpus if node >= 0 else [])
+    except Exception:
+        return None, []
+
+
+def bind_rank_cpus(local_rank, local_world, device_of_rank=None):
+    """Pin this rank's host threads next to its GPU.  device_of_rank[r] = GPU index of local rank r (default: r; all zeros under
+    bench.py --same-device).  With NUMA information: the rank's share of the CPUs of its GPU's node -- the ranks whose GPUs sit on
+    the same node split that node's CPUs (hyper-thread siblings included) in rank order.  Without (no sysfs entry, numa_node ==
+    -1, no GPU): an even contiguous slice of the CPUs this process may already use.  Returns {"numa_node", "cpus": count,
+    "first_cpu", "bound"} for the per-rank diagnostics; never raises (an unsupported platform simply stays unbound).
+
+    The reference is single-process (api/steerable/utils.py:34-50): nothing to mirror, this is the build's own layer."""
+    info = {"numa_node": None, "cpus": 0, "first_cpu": -1, "bound": False}
+    try:
+        allowed = sorted(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        return info
+    info["cpus"], info["first_cpu"] = len(allowed), (allowed[0] if allowed else -1)
+    if local_world <= 1 or not allowed:
+        return info
+    node, local, peers = None, [], list(range(local_world))
+    if device_of_rank is not None and torch.cuda.is_available():
+        nodes = [gpu_numa_cpus(d)[0] for d in device_of_rank]
+        node, local = gpu_numa_cpus(device_of_rank[local_rank])
+        local = [c for c in local if c in set(allowed)]
+        if node is not None and local:
+            peers = [r for r in range(local_world) if nodes[r] == node]
+    pool = local if (node is not None and local) else allowed
+    k, i = len(peers), peers.index(local_rank)
+    per = max(1, len(pool) // k)
+    mine = pool[i * per:(i + 1) * per] if i < k - 1 else pool[i * per:]
+    if not mine:
+        return info
+    try:
+        os.sched_setaffinity(0, mine)
+    except OSError:
+        return info
+    info.update({"numa_node": node if pool is local else None, "cpus": len(mine), "first_cpu": mine[0], "bound": True})
+    return info
+
+
+def all_gather_bytes(local, world, device="cpu"):
+    """Equal-shape all-gather of a uint8 tensor [n, ...] -> [world * n, ...] on `device` (RCCL: device to device).  Used to
+    assemble the synthetic clip pool: every rank generates 1/world of the distinct clip contents, nobody generates one twice."""
+    if not active():
+        return local.to(device)
+    import torch.distributed as dist
+    t = local.to(torch.device(device)).contiguous()
+    if _staged(t):
+        t = t.cpu()
+    out = torch.empty((world * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+    dist.all_gather(list(out.chunk(world, 0)), t)      # views of `out`: every rank's piece lands in place
+    return out
+
+
 def active():
     import torch.distributed as dist
     return dist.is_available() and dist.is_initialized()

@@ -123,11 +123,17 @@ class HotPath(object):
         """Same as forward() but from the raw boundary: uint8 aligned faces [N,112,112,3] on the device
         (37.6 KB/frame over PCIe instead of 0.6 MB of fp32 tensors); PIL-exact preprocessing runs on the GPU,
         chunk by chunk in front of the ResNet50 trunk so the fp32 RGB tensor never exists for more than one chunk."""
+        if frames_u8.dtype != torch.uint8 or frames_u8.dim() != 4 or tuple(frames_u8.shape[1:]) != (112, 112, 3):
+            raise ValueError("frames must be uint8 [N,112,112,3]")
         self._check(plan, frames_u8.shape[0], independent_clips)
         if self._pre is None:
             from .preprocess import FramePreprocessor
             self._pre = FramePreprocessor(phase_size=self.phase_size, device=self.device)
         if not frames_u8.is_cuda:
+            if not frames_u8.is_pinned():
+                # a pageable source makes every non_blocking copy synchronous with the host: nothing would overlap
+                from .stream import pin
+                frames_u8 = pin(frames_u8)
             return self._forward_u8_host(frames_u8, plan)
         N, step = frames_u8.shape[0], self.max_frames_per_call
         if N <= step:
@@ -149,8 +155,6 @@ class HotPath(object):
         per-batch DataLoader feed (api/resnet50_extractor.py:53-72, api/tester.py:65-73).  Same rows as the device-resident
         call, bit for bit (frames are independent through preprocessing and the trunk)."""
         from .stream import FrameStream
-        if frames.dtype != torch.uint8 or tuple(frames.shape[1:]) != (112, 112, 3):
-            raise ValueError("frames must be uint8 [N,112,112,3]")
         N = frames.shape[0]
         chunk = min(self.max_frames_per_call, self.upload_chunk_frames)
         key = torch.cuda.current_stream().cuda_stream
@@ -198,13 +202,25 @@ class HotPath(object):
                 o = self.head.forward([p0, cat], rgb_rows.view(g["bs"], g["T"], 2048), phase_layout="nhwc_cat").view(-1, 2)
             else:
                 # the reference's own form (api/tester.py:122-139): windows gathered per row, pyramid per window frame
+                # The gathered windows are (num_phase + 1) x the frames: run the pyramid over at most max_frames_per_call window
+                # frames at a time (rows are independent through phase_diff_output), so memory follows the chunk, not the video
                 from .phase_difference_extractor import phase_diff_output
-                win = gray[g["f0"]:g["f1"]].index_select(0, g["ids"].reshape(-1).long())
-                win = win.view(g["bs"], g["T"], self.num_phase + 1, self.phase_size, self.phase_size)
-                levels = phase_diff_output(win, self.pde)
-                if len(levels) != 2:
-                    raise ValueError("Two_Stream_RNN takes two pyramid levels (api/mimamo_net.py:133); extract_level gave %d" % len(levels))
-                o = self.head.forward([levels[0].contiguous(), levels[1].contiguous()], rgb_rows.view(g["bs"], g["T"], 2048)).view(-1, 2)
+                P = self.num_phase + 1
+                rows_per = max(1, self.max_frames_per_call // P)
+                src = gray[g["f0"]:g["f1"]]
+                parts = None
+                for r0 in range(0, g["n"], rows_per):
+                    r1 = min(g["n"], r0 + rows_per)
+                    win = src.index_select(0, g["ids"][r0:r1].reshape(-1).long()).view(1, r1 - r0, P, self.phase_size, self.phase_size)
+                    lv = phase_diff_output(win, self.pde)
+                    if len(lv) != 2:
+                        raise ValueError("Two_Stream_RNN takes two pyramid levels (api/mimamo_net.py:133); extract_level gave %d" % len(lv))
+                    if parts is None:
+                        parts = [torch.empty((g["n"],) + tuple(l.shape[2:]), dtype=l.dtype, device=l.device) for l in lv]
+                    for dst, l in zip(parts, lv):
+                        dst[r0:r1] = l[0]
+                levels = [p.view((g["bs"], g["T"]) + tuple(p.shape[1:])) for p in parts]
+                o = self.head.forward(levels, rgb_rows.view(g["bs"], g["T"], 2048)).view(-1, 2)
             if len(groups) == 1 and g["dest"] is None:
                 return o
             if out is None:

@@ -114,3 +114,147 @@ def load_gray_batch(paths, phase_size=48):
         g = g.resize((ow, oh), Image.LANCZOS)
         out[i] = np.asarray(g, dtype=np.float32) / np.float32(255)
     return torch.from_numpy(out)
+
+
+# ---- drop-in Dataset classes (reference names and item layouts) ----------------------------------------------------------------
+class _VideoRecord(object):
+    """Frame list + dummy labels of one processed video (api/sampler/snippet_sampler.py:12-63, test mode)."""
+
+    def __init__(self, video, frames, label_name):
+        self.video = video
+        names = None if label_name is None else ([label_name] if '_' not in label_name else label_name.split("_"))
+        self.label_name = names
+        if len(frames) == 0:
+            raise ValueError("number of frames of video {} should not be zero.".format(video))
+        n_lab = 1 if names is None else len(names)
+        self.path_label = [frames, np.array([[-100] * n_lab] * len(frames))]
+
+
+def _need_test_mode(test_mode, who):
+    if not test_mode:
+        # training-time sampling (annotation files, random flip / crop / colour jitter) is outside the inference hot path
+        # (SURVEY.md section 2: Aff-wild-exps / OMG-exps are out of scope); api/'s own non-test branch of Snippet_Sampler reads
+        # `annot_file` before assigning it (snippet_sampler.py:33-35) and cannot run there either
+        raise NotImplementedError("%s(test_mode=False): training-time sampling is outside this build" % who)
+
+
+class Snippet_Sampler(object):
+    """Drop-in for api/sampler/snippet_sampler.py:66-186 (a map-style dataset: usable with torch.utils.data.DataLoader).
+
+    Same constructor keywords, same `seq_ranges`, same item: `(phase_images [T, num_phase+1, S, S] float32 tensor, rgb features
+    [T, 2048], dummy labels [T, n], np.array([start, end]), video name)` -- `Tester.test_on_dataloader` consumes it unchanged.
+    Differences, both on the host side only: every BMP of a snippet is decoded ONCE (the reference re-opens each frame for every
+    window that contains it, up to 13 times, :156-167), and with `return_u8=True` the item carries the raw boundary instead of
+    the PIL-preprocessed windows: `(frames_u8 [U, h, w, 3] uint8 -- the unique frames of the snippet's windows --, window ids
+    [T, num_phase+1] int32 into them, rgb features, labels, range, name)`, to be resized on the GPU (FramePreprocessor, bit-exact
+    with the PIL path) and fed to Phase_Difference_Extractor.phase_diff_frames."""
+
+    def __init__(self, video_name, root_path, feature_path, annot_dir=None, label_name=None, test_mode=True,
+                 num_phase=12, phase_size=48, length=64, stride=64, verbose=False, return_u8=False):
+        _need_test_mode(test_mode, "Snippet_Sampler")
+        self.video_name, self.root_path, self.feature_path, self.annot_dir = video_name, root_path, feature_path, annot_dir
+        self.label_name, self.test_mode = label_name, test_mode
+        self.length, self.stride, self.num_phase, self.phase_size = length, stride, num_phase, phase_size
+        self.verbose, self.return_u8 = verbose, return_u8
+        self.parse_video()
+
+    def parse_video(self):
+        frames = glob.glob(os.path.join(self.feature_path, '*.npy'))
+        frames = sorted(frames, key=lambda x: os.path.basename(x).split(".")[0])          # :24-25
+        self.video_record = _VideoRecord(self.video_name, frames, self.label_name)
+        if len(frames) < self.length:
+            print("The length exceeds the number of exsisting frames, the sampling length has been changed to {}".format(len(frames)))
+            self.length = self.stride = len(frames)
+        self.seq_ranges = snippet_ranges(len(frames), self.length, self.stride)
+        if self.verbose:
+            print("videos {}, number of seqs:{}".format(self.video_name, len(self.seq_ranges)))
+
+    def __len__(self):
+        return len(self.seq_ranges)
+
+    def _face_path(self, feature_file):
+        f_index = int(os.path.basename(feature_file).split(".")[0])
+        return os.path.join(self.root_path, self.video_record.video + "_aligned", 'frame_det_00_{:06d}.bmp'.format(f_index))
+
+    def __getitem__(self, index):
+        import torch
+        from PIL import Image
+        start, end = self.seq_ranges[index]
+        frames, labels = self.video_record.path_label
+        imgs = np.array([np.load(f) for f in frames[start:end]])
+        ids = window_ids(start, end, len(frames), self.num_phase)                          # [T, num_phase + 1], clamped (:144-152)
+        uniq, inv = np.unique(ids, return_inverse=True)
+        inv = inv.reshape(ids.shape)
+        try:
+            faces = [Image.open(self._face_path(frames[i])) for i in uniq]
+            faces = [f.convert('RGB' if self.return_u8 else 'L') for f in faces]
+        except Exception:
+            raise ValueError("incorrect face path")
+        rng = np.array([start, end])
+        if self.return_u8:
+            u8 = np.stack([np.asarray(f, dtype=np.uint8) for f in faces])
+            return torch.from_numpy(u8), inv.astype(np.int32), imgs, np.array(labels[start:end]), rng, self.video_record.video
+        S = self.phase_size
+        planes = np.empty((len(uniq), S, S), dtype=np.float32)
+        for k, g in enumerate(faces):                                                       # GroupScale(size) + /255 (:177-185)
+            w, h = g.size
+            if not ((w <= h and w == S) or (h <= w and h == S)):
+                ow, oh = (S, int(S * h / w)) if w < h else (int(S * w / h), S)
+                g = g.resize((ow, oh), Image.LANCZOS)
+            if g.size != (S, S):
+                raise ValueError("aligned face is %dx%d: not square, cannot be viewed as %dx%d phase input" % (w, h, S, S))
+            planes[k] = np.asarray(g, dtype=np.float32) / np.float32(255)
+        phase_images = torch.from_numpy(planes[inv])                                        # [T, num_phase + 1, S, S]
+        return phase_images, imgs, np.array(labels[start:end]), rng, self.video_record.video
+
+
+class Image_Sampler(object):
+    """Drop-in for api/sampler/image_sampler.py:64-143: one aligned face per item, `(image, label, frame path, video name)`.
+
+    `transform` is applied to the PIL image as in the reference (Resnet50_Extractor passes the model's own, api/
+    resnet50_extractor.py:53).  With `return_u8=True` the image is the decoded uint8 frame [h, w, 3] (no transform): the raw
+    boundary the GPU preprocessing takes (FramePreprocessor: bilinear 256 + centre crop 224 + 255 x - mean, bit-exact with PIL).
+    Without a transform in test mode the reference builds Resize(size) + ToTensor + ImageNet Normalize (:131-138): reproduced with
+    PIL + numpy (torchvision is not needed)."""
+
+    def __init__(self, video_name, root_path, test_mode=False, annot_dir=None, label_name=None, transform=None, verbose=False,
+                 size=224, return_u8=False):
+        _need_test_mode(test_mode, "Image_Sampler")
+        self.video_name, self.root_path, self.annot_dir, self.label_name = video_name, root_path, annot_dir, label_name
+        self.test_mode, self.transform, self.size, self.verbose, self.return_u8 = test_mode, transform, size, verbose, return_u8
+        self.parse_video()
+
+    def parse_video(self):
+        frames = glob.glob(os.path.join(self.root_path, self.video_name + "_aligned", '*.bmp'))
+        frames = sorted(frames, key=lambda x: os.path.basename(x).split(".")[0].split("_")[-1])   # :26-27
+        self.video_record = _VideoRecord(self.video_name, frames, self.label_name)
+        if self.verbose:
+            print("video {} has {} frames".format(self.video_name, len(frames)))
+        self.frame_ids = np.arange(len(frames))
+
+    def __len__(self):
+        return len(self.frame_ids)
+
+    def _default_transform(self, img):
+        import torch
+        from PIL import Image
+        w, h = img.size
+        s = self.size
+        if not ((w <= h and w == s) or (h <= w and h == s)):
+            img = img.resize((s, int(s * h / w)) if w < h else (int(s * w / h), s), Image.BILINEAR)
+        a = np.asarray(img.convert('RGB'), dtype=np.float32) / np.float32(255)
+        a = (a - np.asarray([0.485, 0.456, 0.406], dtype=np.float32)) / np.asarray([0.229, 0.224, 0.225], dtype=np.float32)
+        return torch.from_numpy(np.ascontiguousarray(a.transpose(2, 0, 1)))
+
+    def __getitem__(self, index):
+        import torch
+        from PIL import Image
+        f_id = self.frame_ids[index]
+        frames, labels = self.video_record.path_label
+        frame, label = frames[f_id], labels[f_id]
+        img = Image.open(frame)
+        if self.return_u8:
+            img = torch.from_numpy(np.asarray(img.convert('RGB'), dtype=np.uint8).copy())
+        else:
+            img = self.transform(img) if self.transform is not None else self._default_transform(img)
+        return img, label, frame, self.video_record.video

@@ -36,6 +36,32 @@ def test_two_ranks_compute_the_same_rows_as_one(tmp_path):
         np.testing.assert_array_equal(two[pos * 64:(pos + 1) * 64], one[clip * 64:(clip + 1) * 64])
 
 
+def test_eight_ranks_on_one_device_whole_job_with_a_ragged_tail(tmp_path):
+    """The shape of the driver's 8-GPU run on the one GPU of the test box: 8 gloo ranks sharing cuda:0 on REAL compute, the whole
+    13-clip queue walked once (ranks 0-4 hold two clips, ranks 5-7 one: their second step is NaN-padded), the clip pool generated
+    once across the job and all-gathered, eight per-rank rows.  Gathered rows of the last step equal the single-rank run."""
+    common = ("--whole-job", "--total-clips", 13, "--distinct-clips", 13, "--warmup", 1, "--no-cpu-baseline", "--no-extra", "--lanes", 1)
+    d8 = _bench("--gpus", 8, "--same-device", "--backend", "gloo", "--clips", 1, "--dump-out", tmp_path / "eight.npy", *common, timeout=1500)
+    d1 = _bench("--gpus", 1, "--clips", 13, "--dump-out", tmp_path / "one.npy", *common)
+    assert d8["n_gpus"] == 8 and d8["steps"] == 2 and d8["scaling"] == "strong" and d1["steps"] == 1
+    pr = d8["per_rank"]
+    assert [x["rank"] for x in pr] == list(range(8)) and all(x["device"] == 0 for x in pr)
+    assert [x["frames"] for x in pr] == [128] * 5 + [64] * 3
+    # 13 contents over 8 ranks: ceil = 2 per rank -> ranks 0-5 generate 2, rank 6 one, rank 7 none; nothing twice
+    assert [x["clip_contents_generated"] for x in pr] == [2, 2, 2, 2, 2, 2, 1, 0]
+    assert all(x["startup_s"] > 0 and x["cpus"] >= 1 for x in pr)
+    print("8 ranks on one device: startup %.1f-%.1f s, cpus per rank %s, bound %s" % (
+        min(x["startup_s"] for x in pr), max(x["startup_s"] for x in pr), sorted({x["cpus"] for x in pr}), sorted({x["numa_node"] is not None for x in pr})))
+    eight, one = np.load(tmp_path / "eight.npy"), np.load(tmp_path / "one.npy")
+    assert eight.shape == (8 * 64, 2) and one.shape == (13 * 64, 2) and np.isfinite(one).all()
+    for r in range(8):                       # last step: rank r's second clip is clip 8 + r (c mod 8 == r), ranks 5-7 have none
+        rows = eight[r * 64:(r + 1) * 64]
+        if r < 5:
+            np.testing.assert_array_equal(rows, one[(8 + r) * 64:(9 + r) * 64])
+        else:
+            assert np.isnan(rows).all()
+
+
 def test_one_rank_process_group_over_rccl():
     """The broadcast / all-gather / barrier / max-reduce path on RCCL itself (a one-rank group is all a 1-GPU box allows)."""
     d = _bench("--gpus", 1, "--force-dist", "--steps", 2, "--warmup", 1, "--clips", 2, "--no-cpu-baseline", "--no-extra")

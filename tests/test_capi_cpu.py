@@ -155,3 +155,13 @@ def test_measurement_modes_are_not_in_the_default_library(L):
     blob = open(os.path.join(ROOT, "mimamo-net_amd", "libmimamo_hip.so"), "rb").read()
     assert b"MM_PF_ABLATE" not in blob and b"MM_PF_LDS_PAD" not in blob
     assert b"MM_TAIL_SPLIT" in blob      # A/B knobs whose results are correct stay (sanity check of the string search)
+
+
+def test_head_blob_size_query_agrees_with_create_on_error_codes(L):
+    units = (ctypes.c_int * 3)(2048, 256, 256)
+    assert L.mm_head_blob_floats_cfg(3, units, 12) == L.mm_head_blob_floats() > 0
+    assert L.mm_head_blob_floats_cfg(3, units, 6) > 0
+    for bad in (5, 33, 40):          # odd / more than 32 differences: what mm_head_create_cfg answers too (header)
+        assert L.mm_head_blob_floats_cfg(3, units, bad) == -3, bad
+    assert L.mm_head_blob_floats_cfg(3, units, 0) == -1
+    assert L.mm_head_blob_floats_cfg(1, units, 12) == -1

@@ -156,6 +156,37 @@ def test_bench_eight_ranks_report_one_row_per_rank():
     assert all(x["ms_per_step"] >= x["ms_per_step_local"] >= 0 and x["queue_broadcast_ms"] >= 0 for x in pr)
     assert abs(max(x["ms_per_step"] for x in pr) - d["ms_per_step"]) < 1e-6          # the headline time IS the slowest rank's
     assert d["value"] == pytest.approx(8 * 2 * 2 * 64 / (d["ms_per_step"] * 2 * 1e-3), rel=1e-6)
+    # round 4: every rank reports where its start-up time went and which CPUs it was pinned to (no NUMA information without a
+    # GPU: the allowed CPUs are split evenly; disjoint slices, together no more than the host has)
+    ncpu = len(os.sched_getaffinity(0))
+    assert all(x["startup_s"] >= x["process_group_init_s"] >= 0 and x["weights_s"] >= 0 for x in pr)
+    assert all(x["cpus"] >= 1 and x["numa_node"] is None for x in pr)
+    if ncpu >= 8:
+        firsts = [x["first_cpu"] for x in pr]
+        assert len(set(firsts)) == 8 and sum(x["cpus"] for x in pr) == ncpu, (firsts, ncpu)
+
+
+def test_bind_rank_cpus_splits_the_allowed_cpus(tmp_path):
+    """dist.bind_rank_cpus in a child process (it changes the caller's affinity): even, disjoint, covering slices of the allowed
+    CPUs when the platform has no NUMA information; a single rank stays unbound."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys, os, json; sys.path.insert(0, %r); import mimamo_net_amd; from mimamo_net_amd import dist; "
+            "a = sorted(os.sched_getaffinity(0)); r, w = int(sys.argv[1]), int(sys.argv[2]); i = dist.bind_rank_cpus(r, w); "
+            "print(json.dumps({'info': i, 'before': a, 'after': sorted(os.sched_getaffinity(0))}))" % root)
+    outs = [json.loads(subprocess.run([sys.executable, "-c", code, str(r), "3"], stdout=subprocess.PIPE, universal_newlines=True,
+                                      check=True).stdout.splitlines()[-1]) for r in range(3)]
+    allowed = outs[0]["before"]
+    if len(allowed) >= 3:
+        got = [o["after"] for o in outs]
+        assert sorted(c for g in got for c in g) == allowed and all(o["info"]["bound"] and o["info"]["cpus"] == len(o["after"]) for o in outs)
+    one = json.loads(subprocess.run([sys.executable, "-c", code, "0", "1"], stdout=subprocess.PIPE, universal_newlines=True,
+                                    check=True).stdout.splitlines()[-1])
+    assert one["after"] == one["before"] and not one["info"]["bound"]
+    from mimamo_net_amd import dist
+    assert dist._parse_cpulist("0-3,8,10-11\n") == [0, 1, 2, 3, 8, 10, 11]
 
 
 def test_bench_gpus_flag_must_match_launcher_world_size():
@@ -201,3 +232,87 @@ def test_bench_under_torchrun_as_the_driver_launches_it():
     assert len(lines) == 1
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["steps"] == 2 and d["config"]["work_queue"]["total_clips"] == 10000
+
+
+# ---- drop-in Dataset classes (Snippet_Sampler / Image_Sampler by name), pinned by the fixtures frozen from the real classes ----------
+def _video_tree(d, n, side, value_of=None, clip=None):
+    from PIL import Image
+    feat, root = os.path.join(d, "feat"), os.path.join(d, "v_opface")
+    os.makedirs(feat)
+    os.makedirs(os.path.join(root, "v_aligned"))
+    for i in range(1, n + 1):
+        np.save(os.path.join(feat, "%05d.npy" % i), np.full((4,), i, dtype=np.float32))
+        img = clip[i - 1] if clip is not None else np.full((side, side, 3), value_of(i), dtype=np.uint8)
+        Image.fromarray(img, "RGB").save(os.path.join(root, "v_aligned", "frame_det_00_%06d.bmp" % i))
+    return root, feat
+
+
+def test_snippet_sampler_dataset_matches_the_real_class(golden, tmp_path):
+    """mimamo_net_amd.Snippet_Sampler on the directory trees tests/golden/make_golden.py built for the real class (G7, G12): same
+    seq_ranges, same clamped windows (constant frames encode their index), same PIL-preprocessed planes; the uint8 mode hands
+    the unique frames + window ids that reproduce the same windows."""
+    import mimamo_net_amd
+    from mimamo_net_amd import Snippet_Sampler
+    g7, g12 = golden("sampler"), golden("sampler_keywords")
+    cases = [(n, 64, 64, 12, "%d" % n, g7, 16) for n in (10, 100, 309)] + \
+            [(int(n), int(l), int(s), int(p), "%d_%d_%d_%d" % (n, l, s, p), g12, 8) for n, l, s, p in g12["cases"] if n <= 100]
+    for k, (n, length, stride, num_phase, tag, g, side) in enumerate(cases):
+        d = str(tmp_path / ("v%d" % k))
+        os.makedirs(d)
+        root, feat = _video_tree(d, n, side, value_of=lambda i: (i - 1) % 251)
+        ds = Snippet_Sampler("v", root, feat, annot_dir=None, label_name="valence_arousal", test_mode=True, num_phase=num_phase,
+                             phase_size=8, length=length, stride=stride)
+        np.testing.assert_array_equal(np.array(ds.seq_ranges), g["ranges_" + tag])
+        du = Snippet_Sampler("v", root, feat, label_name="valence_arousal", num_phase=num_phase, phase_size=8, length=length,
+                             stride=stride, return_u8=True)
+        for j in range(len(ds)):
+            ph, feats, lab, rng, name = ds[j]
+            assert name == "v" and tuple(ph.shape) == (rng[1] - rng[0], num_phase + 1, 8, 8) and lab.shape == (rng[1] - rng[0], 2)
+            assert (lab == -100).all() and np.array_equal(feats[:, 0].astype(np.int64) - 1, np.arange(rng[0], rng[1]))
+            np.testing.assert_array_equal(np.rint(ph[:, :, 0, 0].numpy() * 255).astype(np.int64), g["ids_" + tag][j])
+            u8, ids, feats2, _, rng2, _ = du[j]
+            assert u8.dtype.is_floating_point is False and u8.shape[1:] == (side, side, 3) and list(rng2) == list(rng)
+            np.testing.assert_array_equal(u8.numpy()[ids][:, :, 0, 0, 0].astype(np.int64), g["ids_" + tag][j])
+            assert len(np.unique(ids)) == u8.shape[0]            # every frame of the snippet's windows decoded once
+    # the preprocessing itself: textured 112x112 frames -> convert('L') + Lanczos 48 + /255, bit-equal to the real sampler
+    from mimamo_net_amd import synthetic
+    d = str(tmp_path / "tex")
+    os.makedirs(d)
+    root, feat = _video_tree(d, 3, 112, clip=synthetic.make_clip_u8(5, 3))
+    ph = Snippet_Sampler("v", root, feat, label_name="valence_arousal")[0][0].numpy()
+    np.testing.assert_array_equal(np.stack([ph[0, 6], ph[1, 6], ph[2, 6]]), g7["gray48_clip5"])
+    with pytest.raises(NotImplementedError):
+        Snippet_Sampler("v", root, feat, test_mode=False)
+    with pytest.raises(ValueError):
+        Snippet_Sampler("v", root, str(tmp_path / "nowhere"))
+
+
+def test_image_sampler_dataset(tmp_path):
+    from mimamo_net_amd import Image_Sampler, synthetic, sampler
+    clip = synthetic.make_clip_u8(7, 4)
+    d = str(tmp_path / "img")
+    os.makedirs(d)
+    root, _ = _video_tree(d, 4, 112, clip=clip)
+    ds = Image_Sampler("v", root, test_mode=True, return_u8=True)
+    assert len(ds) == 4
+    for i in range(4):
+        img, label, path, name = ds[i]
+        assert name == "v" and path.endswith("frame_det_00_%06d.bmp" % (i + 1)) and list(label) == [-100]
+        np.testing.assert_array_equal(img.numpy(), clip[i])
+    # with the extractor's transform (api/resnet50_extractor.py:41,53): same tensors as the host loader of Resnet50_Extractor.run
+    paths = [p for _, p in sampler.list_aligned_frames(root, "v")]
+    want = sampler.load_rgb_batch(paths).numpy()
+
+    def model_transform(im):      # Resize(256) + CenterCrop(224) + ToTensor + x255 + Normalize(mean, 1)  (utils/model_utils.py:26-40)
+        import torch
+        from PIL import Image
+        im = im.convert('RGB').resize((256, 256), Image.BILINEAR).crop((16, 16, 240, 240))
+        a = np.asarray(im, dtype=np.float32) / np.float32(255)
+        return torch.from_numpy(a.transpose(2, 0, 1) * np.float32(255.0) - np.asarray(sampler.RESNET50_MEAN, dtype=np.float32)[:, None, None])
+
+    dt = Image_Sampler("v", root, test_mode=True, transform=model_transform)
+    np.testing.assert_array_equal(np.stack([dt[i][0].numpy() for i in range(4)]), want)
+    default = Image_Sampler("v", root, test_mode=True, size=112)[0][0]
+    assert tuple(default.shape) == (3, 112, 112) and abs(float(default.mean())) < 3.0
+    with pytest.raises(NotImplementedError):
+        Image_Sampler("v", root)                 # the reference's default is test_mode=False: training-time sampling

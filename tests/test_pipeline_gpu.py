@@ -107,6 +107,52 @@ def test_tester_reads_reference_directory_layout(tester, oracle, tmp_path):
         tester.test(str(tmp_path / "missing.mp4"))
 
 
+def test_reference_flow_through_the_drop_in_datasets(tester, oracle, tmp_path):
+    """The reference's own flow (api/tester.py:53-75) with this build's classes of the same names: Resnet50_Extractor.run writes the
+    %05d.npy features, Snippet_Sampler (+ torch DataLoader) yields the windowed snippets, Tester.test_on_dataloader runs them --
+    equal to Tester.test's fused path within fp32 regrouping, and to the oracle within the contract.  The uint8 mode of the
+    dataset feeds the GPU preprocessing + the de-duplicated phase kernels and gives the fused path's rows bit for bit."""
+    from PIL import Image
+    from mimamo_net_amd import Snippet_Sampler, Image_Sampler
+    n = 40
+    clip = synthetic.make_clip_u8(61, n)
+    al = tmp_path / "v_opface" / "v_aligned"
+    os.makedirs(al)
+    for i, f in enumerate(clip):
+        Image.fromarray(f, "RGB").save(str(al / ("frame_det_00_%06d.bmp" % (i + 1))))
+    feat = tmp_path / "v_pool5"
+    tester.resnet50_extractor.run(str(tmp_path / "v_opface"), str(feat), video_name="v")
+    ds = Snippet_Sampler("v", str(tmp_path / "v_opface"), str(feat), annot_dir=None, label_name="valence_arousal", test_mode=True,
+                         num_phase=12, phase_size=48, length=16, stride=16)
+    assert len(ds) == 3 and ds.seq_ranges == [[0, 16], [16, 32], [24, 40]]
+    loader = torch.utils.data.DataLoader(ds, batch_size=64, num_workers=0)
+    res = tester.test_on_dataloader(loader)["v"].values
+    want = _oracle_video(oracle, clip, length=16, stride=16)
+    assert res.shape == (n, 2) and np.abs(res - want).max() < OUT_ATOL, np.abs(res - want).max()
+    # the raw-boundary mode: unique uint8 frames + window ids per snippet -> GPU preprocessing -> de-duplicated phase kernels
+    du = Snippet_Sampler("v", str(tmp_path / "v_opface"), str(feat), label_name="valence_arousal", length=16, stride=16, return_u8=True)
+    from mimamo_net_amd.preprocess import FramePreprocessor
+    pre = FramePreprocessor(device=tester.device)
+    p0s, p1s, rgbs, ranges = [], [], [], []
+    with torch.no_grad():
+        for k in range(len(du)):
+            u8, ids, feats, _, rng, _ = du[k]
+            gray, _ = pre(u8.to(tester.device), want_rgb=False)
+            p0, p1 = tester.phase_difference_extractor.phase_diff_frames(gray, torch.from_numpy(ids).to(tester.device))
+            p0s.append(p0); p1s.append(p1); rgbs.append(torch.from_numpy(feats).to(tester.device)); ranges.append(list(rng))
+        out = tester.model([torch.stack(p0s), torch.stack(p1s)], torch.stack(rgbs)).cpu().numpy()     # bs = 3 snippets: GRU over them
+    got = sampler.assemble(list(out), ranges, 2)
+    assert np.abs(got - want).max() < OUT_ATOL
+    assert np.abs(got - res).max() < 2e-5          # windowed (literal kernels) vs de-duplicated (fused kernels) form
+    # Image_Sampler hands the extractor the frames it decoded: same features as run() wrote
+    im = Image_Sampler("v", str(tmp_path / "v_opface"), test_mode=True, return_u8=True)
+    u8 = torch.stack([im[i][0] for i in range(4)]).to(tester.device)
+    with torch.no_grad():
+        _, rgb3 = pre(u8, want_gray=False, bordered3=True)
+        f4 = tester.resnet50_extractor.get_vec(rgb3).cpu().numpy()
+    np.testing.assert_array_equal(f4, np.stack([np.load(str(feat / ("%05d.npy" % (i + 1)))) for i in range(4)]))
+
+
 def test_lanes_on_several_streams_are_bit_identical(tester):
     """Videos spread over HIP streams (shared handles, per-stream workspaces) == single-stream pass."""
     lengths = [64, 100, 64, 30]
