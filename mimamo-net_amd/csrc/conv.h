@@ -58,6 +58,11 @@ int wino_output_transform(const float* M, const float* bias, float* y, int B, in
 // Needs Cin % 64 == 0 and Cout % 32 == 0 (MM_ERR_UNSUPPORTED otherwise).
 int wino_gemm_output_fused(const float* V, const float* U, const float* bias, float* y, int B, int H, int W, int Cin, int Cout,
                            int relu, int shape, hipStream_t s);
+// The same kernel with the residual block's 1x1 increase conv inside its epilogue (Cout == 64, C2 == 256: conv2_x blocks 2, 3):
+// out [B,H,W,C2] = relu( W2 relu(conv3x3(x) + bias) + bias2 + res ); the 64-channel tensor in between never reaches HBM.
+int wino_gemm_output_fused_inc(const float* V, const float* U, const float* bias, const float* W2, const float* bias2, const float* res,
+                               float* out, int B, int H, int W, int Cin, int Cout, int C2, int relu, hipStream_t s);
+bool wino_fused_inc_supported(int64_t ntile, int Cin, int Cout, int C2);
 // whether wino_gemm_output_fused takes the shape (channel granularity, 32-bit offsets inside a position plane)
 bool wino_fused_supported(int64_t ntile, int Cin, int Cout);
 

@@ -213,7 +213,11 @@ static int run_layer_dual(const Layer& L, const float* in, int B, int H, int W, 
 static int g_wino_fused_max_cin = 256;   // measurement knob (MM_WF_MAX_CIN)
 static int g_wino_fused_shape = 0;   // measurement knob (MM_WINO_FUSED_SHAPE): workgroup shape of the fused kernel, 0 = auto
 
-static int run_layer_wino(const Layer& L, const float* in, int B, int H, int W, float* out, float* V, float* M, int m, hipStream_t s) {
+// inc / inc_res / inc_out (optional, fused form only): the residual block's increase layer applied inside the fused kernel --
+// inc_out [B,H,W,inc->cout] = relu(inc(relu(L(in))) + inc_res); `out` is then not written.  Returns MM_ERR_UNSUPPORTED (before
+// anything is launched) when the shape is not the one wino_fused.hip's INC instantiation takes.
+static int run_layer_wino(const Layer& L, const float* in, int B, int H, int W, float* out, float* V, float* M, int m, hipStream_t s,
+                          const Layer* inc = nullptr, const float* inc_res = nullptr, float* inc_out = nullptr) {
     const int mt = m == 5 ? 4 : m;
     const int TH = (H + mt - 1) / mt, TW = (W + mt - 1) / mt, npos = (mt + 2) * (mt + 2);
     const int64_t ntile = (int64_t)B * TH * TW;
@@ -224,8 +228,14 @@ static int run_layer_wino(const Layer& L, const float* in, int B, int H, int W, 
     if (wc != L.cin_p && m != 4) return MM_ERR_UNSUPPORTED;
     // no plane set for the three-kernel form and the fused kernel declines the shape: say so before transforming anything
     if (!M && !(fused && wino_fused_supported(ntile, wc, L.cout))) return MM_ERR_UNSUPPORTED;
+    if (inc && !(fused && inc->k == 1 && inc->stride == 1 && inc->Kpad == L.cout && inc->korder == 0 && inc->relu && !inc->ps &&
+                 wino_fused_inc_supported(ntile, wc, L.cout, inc->cout)))
+        return MM_ERR_UNSUPPORTED;
     int rc = wino_input_transform(in, V, B, H, W, wc, m, s, L.cin_p);
     if (rc != MM_OK) return rc;
+    if (inc)
+        return wino_gemm_output_fused_inc(V, L.wino_u4, L.bias, inc->w, inc->bias, inc_res, inc_out, B, H, W, wc, L.cout, inc->cout,
+                                          L.relu, s);
     if (fused) {
         rc = wino_gemm_output_fused(V, L.wino_u4, L.bias, out, B, H, W, wc, L.cout, L.relu, g_wino_fused_shape, s);
         if (rc != MM_ERR_UNSUPPORTED) return rc;
@@ -275,6 +285,7 @@ struct mm_resnet50 {
     int ceil_mode;
     int winograd;  // 0 direct, 2 = F(2x2,3x3), 4 = F(4x4,3x3) for the layers that have Winograd-domain weights
     int fuse_proj; // 1 (default): the first block of a stage runs increase + projection as one launch
+    int fuse_inc;  // 1 (default): conv2_x blocks without a projection run 3x3 + increase + residual in ONE kernel (wino_fused.hip INC)
     int device;
 };
 
@@ -387,6 +398,8 @@ int mm_resnet50_create(mm_resnet50_t** out, const float* blob, int64_t n_floats,
     {
         const char* fp = getenv("MM_FUSE_PROJ");   // measurement knob: 0 = projection shortcut as its own launch + residual read
         h->fuse_proj = fp ? atoi(fp) : 1;
+        const char* fi = getenv("MM_FUSE_INC");    // measurement knob: 0 = 3x3 and increase conv as separate launches (the parity twin)
+        h->fuse_inc = fi ? atoi(fi) : 1;
     }
     auto conv_bn = [&](Layer& L, int cout, int cin, int k, int stride, int pad, int relu) {
         const float* w = p;
@@ -525,15 +538,24 @@ int mm_resnet50_forward(mm_resnet50_t* h, const float* images, int nchw, int64_t
         // position GEMMs are matrix-core bound, 135 vs 109 TFLOP/s, and its M planes are small); per layer in DESIGN.md
         const int wm_ = h->winograd == 1 ? (Bk.conv3.cin <= g_wino_fused_max_cin ? 5 : 4) : h->winograd;
         const int wt_ = wm_ == 5 ? 4 : wm_;   // tile side of the variant
+        bool inc_done = false;
         if (wm_ && Bk.conv3.wino_u &&
             (int64_t)(wt_ + 2) * (wt_ + 2) * ((H1 + wt_ - 1) / wt_) * ((W1 + wt_ - 1) / wt_) * Bk.conv3.cin <= kRsWino) {
-            rc = run_layer_wino(Bk.conv3, y1, B, H1, W1, y2, wv, wm, wm_, s);
+            rc = MM_ERR_UNSUPPORTED;
+            if (wm_ == 5 && h->fuse_inc && !Bk.has_proj) {
+                // conv2_x blocks 2, 3 (Cin = Cout = 64 -> 256): 3x3 + increase + residual + ReLU in one kernel
+                rc = run_layer_wino(Bk.conv3, y1, B, H1, W1, nullptr, wv, nullptr, 5, s, &Bk.increase, x, o);
+                inc_done = rc == MM_OK;
+            }
+            if (rc == MM_ERR_UNSUPPORTED) rc = run_layer_wino(Bk.conv3, y1, B, H1, W1, y2, wv, wm, wm_, s);
             H2 = H1; W2 = W1;
         } else {
             rc = run_layer(Bk.conv3, y1, B, H1, W1, Bk.reduce.cout, 0, y2, Bk.conv3.cout, 0, nullptr, 0, s, &H2, &W2);
         }
         if (rc != MM_OK) return rc;
-        if (dual) {
+        if (inc_done) {
+            H3 = H2; W3 = W2;
+        } else if (dual) {
             // relu(BN(increase(y2)) + BN(proj(x))) in one accumulation: the shortcut tensor is never written or re-read
             rc = run_layer_dual(Bk.inc_proj, y2, B, H2, W2, x, H, W, C, Bk.proj_stride, o, s);
             H3 = H2; W3 = W2;

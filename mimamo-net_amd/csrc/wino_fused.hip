@@ -36,12 +36,22 @@ struct WinoFusedParams {
     float* out;          // NHWC [B][H][W][Cout]
     int ntile, K, Cout, B, H, W, TH, TW, relu, tiles_n;
     float at_cols[24];   // At[q'][q] as [q][q']
+    // INC instantiation only: the residual block's 1x1 increase conv applied to this layer's output before it leaves the CU
+    const float* w2;     // [C2][Cout] BN-folded increase weights (Cout == 64: the workgroup owns every channel of its pixels)
+    const float* bias2;  // [C2]
+    const float* res;    // residual, NHWC [B][H][W][C2]
+    int C2;              // 256
 };
 
 __device__ constexpr float kAt[4][6] = {{1, 1, 1, 1, 1, 0}, {0, 1, -1, 2, -2, 0}, {0, 1, 1, 4, 4, 0}, {0, 1, -1, 8, -8, 1}};
 static constexpr float kAtHost[4][6] = {{1, 1, 1, 1, 1, 0}, {0, 1, -1, 2, -2, 0}, {0, 1, 1, 4, 4, 0}, {0, 1, -1, 8, -8, 1}};
 
-template <int NBUF, int WGM>
+// INC (round 4, conv2_x blocks 2 and 3: Cin = Cout = 64, increase 64 -> 256): the position GEMMs run TRANSPOSED (M^T = U V^T, so a
+// lane holds 4 consecutive channels of ONE tile) and the epilogue contracts relu(Y + bias) with the 64 KB increase matrix straight
+// from the accumulator registers -- in that layout they ARE the B operand of the second MFMA -- adds the residual, applies the ReLU
+// and writes the block's 256-channel output: the 64-channel tensor between the 3x3 and the increase conv (1.6 MB per frame written
+// and re-read) never exists, and the 49 %-busy K = 64 GEMM launch disappears.
+template <int NBUF, int WGM, bool INC = false>
 __global__ void __launch_bounds__(WGM * 128) __attribute__((amdgpu_waves_per_eu(2, 2)))
 wino_fused_kernel(const WinoFusedParams p) {
     // WGM = 4: eight waves, 64 tiles x 64 channels, one workgroup per CU; WGM = 2: four waves, 32 tiles x 64 channels, two
@@ -210,6 +220,20 @@ wino_fused_kernel(const WinoFusedParams p) {
             b1[j] = *reinterpret_cast<const float4*>(sl + fb1[j]);
         }
         if (first) Mc[0] = Mc[1] = f32x4v{0.f, 0.f, 0.f, 0.f};
+        if constexpr (INC) {
+            // transposed product: rows = channels (U), columns = tiles (V) -> C row 4 lg + e = channel, column l16 = tile
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                Mc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(b0[j].x, a[j].x, Mc[0], 0, 0, 0);
+                Mc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(b1[j].x, a[j].x, Mc[1], 0, 0, 0);
+                Mc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(b0[j].y, a[j].y, Mc[0], 0, 0, 0);
+                Mc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(b1[j].y, a[j].y, Mc[1], 0, 0, 0);
+                Mc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(b0[j].z, a[j].z, Mc[0], 0, 0, 0);
+                Mc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(b1[j].z, a[j].z, Mc[1], 0, 0, 0);
+                Mc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(b0[j].w, a[j].w, Mc[0], 0, 0, 0);
+                Mc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(b1[j].w, a[j].w, Mc[1], 0, 0, 0);
+            }
+        } else {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             Mc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j].x, b0[j].x, Mc[0], 0, 0, 0);
@@ -220,6 +244,7 @@ wino_fused_kernel(const WinoFusedParams p) {
             Mc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j].z, b1[j].z, Mc[1], 0, 0, 0);
             Mc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j].w, b0[j].w, Mc[0], 0, 0, 0);
             Mc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j].w, b1[j].w, Mc[1], 0, 0, 0);
+        }
         }
         buf = buf == NBUF - 1 ? 0 : buf + 1;
     };
@@ -253,6 +278,114 @@ wino_fused_kernel(const WinoFusedParams p) {
     update_y(5);
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");   // tail loads drained, everyone done with the ring
 
+    if constexpr (INC) {
+        // ---- second GEMM: out[n2][pixel] = relu( sum_c W2[n2][c] * relu(Y + bias)[c][pixel] + bias2[n2] + res[pixel][n2] ), C2 = 256.
+        // The dead operand ring takes the whole increase matrix (256 rows x 256 B, same XOR-swizzled rows as the slabs) plus an 8 KB
+        // exchange area.  A wave holds 32 of the 64 channels of its 16 tiles; the wave with the other 32 (same tiles: wave ^ 1) gets a
+        // lane-for-lane copy of the registers through LDS -- in the transposed layout the accumulator image of a position IS the B
+        // operand (k = 4 lg + e inside a 16-channel block, any k order is a valid contraction order as long as A uses the same).
+        // Wave (wm, wn) then produces channels [128 wn, 128 wn + 128) of its 16 tiles: lane (l16, lg) ends up with 4 consecutive
+        // output channels of tile l16 per 16-row block -> 16-byte stores and residual loads, 64 contiguous bytes per tile per
+        // instruction, no transpose.
+        static_assert(WGM == 2 && NBUF == 3, "INC is built for the four-wave workgroup");
+        constexpr int W2_FLOATS = 256 * KS;
+        {
+            const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.w2), 0, (unsigned)(W2_FLOATS * 4), 0x00020000);
+#pragma unroll
+            for (int it = 0; it < 256 / (4 * NW); ++it) {
+                const int row = (it * NW + wave) * 4 + (lane >> 4);
+                const unsigned voff = (unsigned)(row * KS + (((lane & 15) ^ (row & 15)) << 2)) * 4u;
+                dma1(rw, voff, lds0 + (unsigned)((it * NW + wave) * 1024));
+            }
+        }
+        float* xb = lds + W2_FLOATS;                                   // [4 waves][2 channel blocks][4 lg][16 l16] float4
+        const int x_own = (wave * 8 + lg) * 64 + l16 * 4, x_par = ((wave ^ 1) * 8 + lg) * 64 + l16 * 4;
+        f32x4v b1[2];
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb) {
+            const float4 t = p.bias ? *reinterpret_cast<const float4*>(p.bias + wn * 32 + cb * 16 + 4 * lg) : float4{0.f, 0.f, 0.f, 0.f};
+            b1[cb] = f32x4v{t.x, t.y, t.z, t.w};
+        }
+        const int tpi = p.TH * p.TW;
+        const int t = m_base + wm * 16 + l16;
+        const bool tok = t < p.ntile;
+        const int tt = tok ? t : 0;
+        const int bimg = tt / tpi, rem = tt - bimg * tpi;
+        const int ty = rem / p.TW, tx = rem - ty * p.TW;
+        const int64_t pix0 = ((int64_t)bimg * p.H + 4 * ty) * p.W + 4 * tx;
+        const int c0 = wn * 128 + 4 * lg;                             // first output channel of this lane (block 0)
+        const float* rbase = p.res + pix0 * p.C2 + c0;
+        float* obase = p.out + pix0 * p.C2 + c0;
+        // A-operand fragment offsets: row n2 = 128 wn + 16 blk + l16, k-quad (8 src_wn + 4 cb + lg) ^ l16
+        int wa[4];
+#pragma unroll
+        for (int sidx = 0; sidx < 4; ++sidx) {
+            const int qd = ((sidx < 2 ? wn : 1 - wn) * 8 + (sidx & 1) * 4 + lg) ^ l16;
+            wa[sidx] = (wn * 128 + l16) * KS + (qd << 2);
+        }
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");   // W2 landed
+#pragma unroll
+        for (int pp = 0; pp < 4; ++pp) {
+#pragma unroll
+            for (int qq = 0; qq < 4; ++qq) {
+#pragma unroll
+                for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float v = Y[pp][qq][cb][e] + b1[cb][e];
+                        Y[pp][qq][cb][e] = p.relu ? fmaxf(v, 0.f) : v;
+                    }
+                if (pp | qq) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // the previous position's copies have been read
+#pragma unroll
+                for (int cb = 0; cb < 2; ++cb) *reinterpret_cast<f32x4v*>(xb + x_own + cb * 256) = Y[pp][qq][cb];
+                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                f32x4v Pr[2];
+#pragma unroll
+                for (int cb = 0; cb < 2; ++cb) Pr[cb] = *reinterpret_cast<const f32x4v*>(xb + x_par + cb * 256);
+                const bool pok = tok && 4 * ty + pp < p.H && 4 * tx + qq < p.W;
+                const int64_t poff = ((int64_t)pp * p.W + qq) * p.C2;
+                const float* rp = pok ? rbase + poff : p.res + c0;       // a clipped pixel reads a valid address and stores nothing
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    f32x4v rs[4], bs[4], acc[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int n2 = h * 64 + j * 16;
+                        rs[j] = *reinterpret_cast<const f32x4v*>(rp + n2);
+                        bs[j] = *reinterpret_cast<const f32x4v*>(p.bias2 + c0 + n2);
+                        acc[j] = f32x4v{0.f, 0.f, 0.f, 0.f};
+                    }
+#pragma unroll
+                    for (int sidx = 0; sidx < 4; ++sidx) {
+                        const f32x4v Bv = sidx < 2 ? Y[pp][qq][sidx & 1] : Pr[sidx & 1];
+                        float4 w4[4];
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) w4[j] = *reinterpret_cast<const float4*>(lds + wa[sidx] + (h * 64 + j * 16) * KS);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(w4[j].x, Bv[0], acc[j], 0, 0, 0);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(w4[j].y, Bv[1], acc[j], 0, 0, 0);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(w4[j].z, Bv[2], acc[j], 0, 0, 0);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(w4[j].w, Bv[3], acc[j], 0, 0, 0);
+                    }
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        acc[j] = acc[j] + bs[j] + rs[j];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) acc[j][e] = fmaxf(acc[j][e], 0.f);
+                    }
+                    if (pok) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            __builtin_nontemporal_store(acc[j], reinterpret_cast<f32x4v*>(obase + poff + h * 64 + j * 16));
+                    }
+                }
+            }
+        }
+        return;
+    }
     // ---- epilogue.  MFMA C layout: column (channel) = l16 (+ 16 per channel block), row (tile) = 4 lg + e.  Each wave transposes
     //      one output pixel position at a time through its private 16 x 36-float staging rows and then owns 4 consecutive channels
     //      of a tile per lane: 16-byte stores, 128 contiguous bytes per tile.
@@ -303,15 +436,16 @@ wino_fused_kernel(const WinoFusedParams p) {
     }
 }
 
-template <int NBUF, int WGM>
+template <int NBUF, int WGM, bool INC = false>
 static int launch_fused(WinoFusedParams p, hipStream_t s) {
     constexpr int BM = 16 * WGM;
     constexpr int LDS_BYTES = NBUF * (BM + 64) * 64 * 4;
+    static_assert(!INC || LDS_BYTES >= (256 * 64 + 2048) * 4, "INC: increase matrix + exchange area live in the dead ring");
     static bool attr_set[16] = {};
     int dev = 0;
     (void)hipGetDevice(&dev);
     if (dev >= 0 && dev < 16 && !attr_set[dev]) {
-        MM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(wino_fused_kernel<NBUF, WGM>), hipFuncAttributeMaxDynamicSharedMemorySize,
+        MM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(wino_fused_kernel<NBUF, WGM, INC>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                    LDS_BYTES));
         attr_set[dev] = true;
     }
@@ -322,10 +456,12 @@ static int launch_fused(WinoFusedParams p, hipStream_t s) {
     if (blocks <= 0 || blocks > 0x7fffffff) return MM_ERR_INVALID_ARG;
     if (prof_enabled()) {
         char tag[64];
-        snprintf(tag, sizeof(tag), "wino-fused M=%d K=%d N=%d t%dx64 b36", p.ntile, p.K, p.Cout, BM);
-        prof_before(0, 2.0 * 36.0 * (double)p.ntile * (double)p.K * (double)p.Cout, s, tag);
+        snprintf(tag, sizeof(tag), "wino-fused%s M=%d K=%d N=%d t%dx64 b36", INC ? "+inc256" : "", p.ntile, p.K, p.Cout, BM);
+        double fl = 2.0 * 36.0 * (double)p.ntile * (double)p.K * (double)p.Cout;
+        if (INC) fl += 2.0 * (double)p.B * p.H * p.W * (double)p.Cout * (double)p.C2;
+        prof_before(0, fl, s, tag);
     }
-    hipLaunchKernelGGL((wino_fused_kernel<NBUF, WGM>), dim3((unsigned)blocks), dim3(WGM * 128), LDS_BYTES, s, p);
+    hipLaunchKernelGGL((wino_fused_kernel<NBUF, WGM, INC>), dim3((unsigned)blocks), dim3(WGM * 128), LDS_BYTES, s, p);
     prof_after(0, s);
     MM_LAUNCH_CHECK();
     return MM_OK;
@@ -337,11 +473,16 @@ bool wino_fused_supported(int64_t ntile, int Cin, int Cout) {
     return (ntile + 64) * Cin * 4 < 0xFFFFF000ll && ((int64_t)Cout + 64) * Cin * 4 < 0xFFFFF000ll;
 }
 
+bool wino_fused_inc_supported(int64_t ntile, int Cin, int Cout, int C2) {
+    return Cout == 64 && C2 == 256 && wino_fused_supported(ntile, Cin, Cout);
+}
+
 // V [36][ntile][Cin] (from wino_input_transform, m = 4), U [36][Cout][Cin] -> y NHWC [B,H,W,Cout] (+bias, ReLU)
 int wino_gemm_output_fused(const float* V, const float* U, const float* bias, float* y, int B, int H, int W, int Cin, int Cout,
                             int relu, int shape, hipStream_t s) {
     WinoFusedParams p;
     p.V = V; p.U = U; p.bias = bias; p.out = y;
+    p.w2 = nullptr; p.bias2 = nullptr; p.res = nullptr; p.C2 = 0;
     p.TH = (H + 3) / 4; p.TW = (W + 3) / 4;
     const int64_t ntile = (int64_t)B * p.TH * p.TW;
     if (!wino_fused_supported(ntile, Cin, Cout)) return MM_ERR_UNSUPPORTED;
@@ -351,6 +492,22 @@ int wino_gemm_output_fused(const float* V, const float* U, const float* bias, fl
     // workgroup per CU -- no common barrier between the two waves of a SIMD, prologue / epilogue of one workgroup under the
     // other's main loop); 8 = eight waves (64 x 64), 3-deep ring; 4 = eight waves, 4-deep ring
     return shape == 4 ? launch_fused<4, 4>(p, s) : shape == 8 ? launch_fused<3, 4>(p, s) : launch_fused<3, 2>(p, s);
+}
+
+// The 3x3 layer AND the block's increase conv: V, U as above with Cout == 64;  out [B,H,W,C2] = relu( W2 relu(conv3x3 + bias) +
+// bias2 + res ), W2 [C2][64] (BN folded), res NHWC [B,H,W,C2], C2 == 256.  MM_ERR_UNSUPPORTED for any other shape.
+int wino_gemm_output_fused_inc(const float* V, const float* U, const float* bias, const float* W2, const float* bias2, const float* res,
+                               float* out, int B, int H, int W, int Cin, int Cout, int C2, int relu, hipStream_t s) {
+    if (!V || !U || !W2 || !bias2 || !res || !out) return MM_ERR_INVALID_ARG;
+    WinoFusedParams p;
+    p.V = V; p.U = U; p.bias = bias; p.out = out;
+    p.w2 = W2; p.bias2 = bias2; p.res = res; p.C2 = C2;
+    p.TH = (H + 3) / 4; p.TW = (W + 3) / 4;
+    const int64_t ntile = (int64_t)B * p.TH * p.TW;
+    if (!wino_fused_inc_supported(ntile, Cin, Cout, C2)) return MM_ERR_UNSUPPORTED;
+    if (ntile <= 0) return MM_OK;
+    p.ntile = (int)ntile; p.K = Cin; p.Cout = Cout; p.B = B; p.H = H; p.W = W; p.relu = relu; p.tiles_n = 0;
+    return launch_fused<3, 2, true>(p, s);
 }
 
 }  // namespace mm

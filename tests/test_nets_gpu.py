@@ -621,6 +621,47 @@ def test_resnet50_fused_projection_blocks(resnet, oracle, dev, monkeypatch):
         resnet.set_winograd(True)
 
 
+def test_resnet50_increase_conv_inside_the_fused_winograd_kernel(resnet, oracle, dev, monkeypatch):
+    """conv2_x blocks 2 and 3 (round 4): the fused F(4x4,3x3) kernel also applies the block's 64 -> 256 increase conv, the residual
+    add and the ReLU (wino_fused.hip INC: transposed position GEMMs, second MFMA straight from the accumulators) against the
+    separate-launch form (MM_FUSE_INC=0, the parity twin) and the oracle.  Same products, another summation order in the K = 64
+    contraction: not bit-equal, far inside the tolerance.  Batch 3 leaves a ragged last workgroup (588 tiles / 32)."""
+    from mimamo_net_amd.resnet50_extractor import Resnet50_Extractor
+    monkeypatch.setenv("MM_FUSE_INC", "0")
+    split = Resnet50_Extractor(state_dict=weights.make_resnet50_state_dict(seed=0), device=dev)
+    monkeypatch.delenv("MM_FUSE_INC")
+    x = _images(3, 17)
+    want = oracle.resnet50_pool5(weights.make_resnet50_state_dict(seed=0), x)
+    xt = torch.from_numpy(x).to(dev)
+    scale = np.abs(want).max()
+    n_f = _count_conv_launches(lambda: resnet.get_vec(xt))
+    n_s = _count_conv_launches(lambda: split.get_vec(xt))
+    assert n_s - n_f == 2, ("two increase launches fewer with the fused form", n_f, n_s)
+    try:
+        for mode in (1, 5):
+            resnet.set_winograd(mode)
+            split.set_winograd(mode)
+            a, b = resnet.get_vec(xt).cpu().numpy(), split.get_vec(xt).cpu().numpy()
+            assert not np.array_equal(a, b)                      # the knob really switches the schedule
+            d = np.abs(a - b).max() / scale
+            print("winograd %d: fused-increase vs separate launches max rel %.2e; vs oracle %.2e / %.2e" % (
+                mode, d, np.abs(a - want).max() / scale, np.abs(b - want).max() / scale))
+            assert d < 1e-5, d
+            for g in (a, b):
+                mx, mean = np.abs(g - want).max() / scale, np.abs(g - want).mean() / scale
+                assert mx < POOL5_RTOL * 10 and mean < POOL5_RTOL
+                assert mx < POOL5_TIGHT_MAX and mean < POOL5_TIGHT_MEAN, ("regression bound", mx, mean)
+        resnet.set_winograd(4)        # the three-kernel form never takes the fused-increase path
+        split.set_winograd(4)
+        assert torch.equal(resnet.get_vec(xt), split.get_vec(xt))
+    finally:
+        resnet.set_winograd(True)
+    # deterministic, batch-invariant
+    a = resnet.get_vec(xt)
+    assert torch.equal(a, resnet.get_vec(xt))
+    assert (resnet.get_vec(xt[1:2].contiguous()) - a[1:2]).abs().max().item() / scale < 1e-5
+
+
 def test_phasenet_winograd_layers_vs_direct_form(head, oracle, dev, monkeypatch):
     """PhaseNet's stride-1 3x3 layers with >= 64 input channels (88 -> 128 at 24x24 -- K padded to 128 with zero columns -- and
     128 -> 256 at 12x12) run through the fused F(4x4,3x3) kernel; MM_HEAD_WINOGRAD=0 keeps them in the direct implicit-GEMM form.
