@@ -559,10 +559,13 @@ def run_rank(args):
     # ---- roofline leg: hipEvent-timed launches of one more step (same stream), by kernel category
     from mimamo_net_amd import _lib
     L = _lib.lib()
-    ms = (ctypes.c_double * 4)()
-    work_ = (ctypes.c_double * 4)()
-    launches = (ctypes.c_int64 * 4)()
+    ms = (ctypes.c_double * 5)()
+    work_ = (ctypes.c_double * 5)()
+    launches = (ctypes.c_int64 * 5)()
     ids0 = content(timed[0] if timed[0] else warm[0] if warm else mine[:per_step])
+    import tempfile
+    dump_path = os.path.join(tempfile.mkdtemp(prefix="mm_prof_"), "launches.csv")
+    os.environ["MM_PROF_DUMP"] = dump_path          # per-launch rows (category, work, ms, tag) for the mixed roofline below
     with torch.no_grad():
         comp.step(ids0, lanes=1)
         comp.sync()
@@ -572,6 +575,15 @@ def run_rank(args):
         comp.step(ids0, lanes=1)
         rc = L.mm_profile_end(ms, work_, launches)
     assert rc == 0
+    os.environ.pop("MM_PROF_DUMP", None)
+    live = []
+    try:
+        with open(dump_path) as f:
+            for line in f:
+                c_, w_, t_, tag_ = line.rstrip("\n").split(",", 3)
+                live.append((int(c_), float(w_), float(t_), tag_))
+    except OSError:
+        pass
     conv_tflops = work_[0] / (ms[0] * 1e-3) / 1e12
     phase_ms = ms[1] + ms[2]
     phase_gbs = (work_[1] + work_[2]) / (phase_ms * 1e-3) / 1e9
@@ -592,6 +604,41 @@ def run_rank(args):
 
     traffic, traffic_file = committed_traffic("conv")
     ptraffic, ptraffic_file = committed_traffic("phase")
+
+    def mixed_roofline():
+        """Sum over the launches of this step of max(FLOPs / MFMA peak, HBM bytes / HBM peak) against the sum of their measured
+        (live, hipEvent) times: the fraction of the LIMITING roofline per launch.  FLOPs and times are live; the
+        HBM bytes per launch are rocprofv3 PMC counters (tools/layer_roofline.sh) committed under profiles/ for these kernel
+        sources (hash) -- they cannot be read without the profiler."""
+        import glob
+        for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*layer_bytes*.json")), reverse=True):
+            try:
+                with open(path) as f:
+                    lb = json.load(f)
+            except (OSError, ValueError):
+                continue
+            if lb.get("kernel_source_hash") != kernel_source_hash() or lb.get("clips_per_gpu") != per_step:
+                continue
+            rows = lb["launches"]
+            if len(rows) != len(live) or any(r["tag"] != l[3] or r["cat"] != l[0] for r, l in zip(rows, live)):
+                return None, "profiles/%s lists other launches than this step ran (%d vs %d)" % (os.path.basename(path), len(rows), len(live))
+            floor = meas = 0.0
+            by_bound = {"mfma": [0.0, 0.0], "hbm": [0.0, 0.0]}
+            for r, (c_, w_, t_, _) in zip(rows, live):
+                t_m = (w_ if c_ == 0 else 0.0) / (PEAK_FP32_MFMA_TFLOPS * 1e12) * 1e3
+                t_h = r["pmc_bytes"] / (PEAK_HBM_GBS * 1e9) * 1e3
+                floor += max(t_m, t_h)
+                meas += t_
+                b = by_bound["mfma" if t_m >= t_h else "hbm"]
+                b[0] += max(t_m, t_h)
+                b[1] += t_
+            return {"step_floor_ms": floor, "measured_ms": meas, "mixed_frac": floor / meas, "launches": len(live),
+                    "mfma_bound_launches": {"floor_ms": by_bound["mfma"][0], "measured_ms": by_bound["mfma"][1]},
+                    "hbm_bound_launches": {"floor_ms": by_bound["hbm"][0], "measured_ms": by_bound["hbm"][1]},
+                    "bytes_file": os.path.basename(path)}, None
+        return None, "no per-launch PMC byte list under profiles/ for these kernel sources (hash %s)" % kernel_source_hash()
+
+    mixed, mixed_note = mixed_roofline() if live else (None, "no per-launch dump")
     wino = 0 if args.no_winograd else {1: "F(4x4,3x3); output transform fused into the GEMMs for Cin <= 256", 2: "F(2x2,3x3)", 4: "F(4x4,3x3), three kernels", 5: "F(4x4,3x3), fused everywhere"}.get(args.winograd, args.winograd)
     result["roofline"] = {
         "bound": "mfma", "kernel": "conv_mfma_kernel (fp32 implicit-GEMM conv/GEMM engine, all %d launches of one step)" % launches[0],
@@ -608,10 +655,22 @@ def run_rank(args):
         "algorithmic_equiv_tflops": 8.108e9 * n_frames / ((ms[0] + ms[3]) * 1e-3) / 1e12,
         "algorithmic_equiv_frac": 8.108e9 * n_frames / ((ms[0] + ms[3]) * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS,
         "winograd": wino,
+        # per-launch limiting roofline over EVERY kernel of the step (conv / GEMM, Winograd transforms, phase stage, pools,
+        # preprocessing): sum of max(t_mfma, t_hbm) and its ratio to the sum of the measured launch times
+        "step_floor_ms": mixed["step_floor_ms"] if mixed else None,
+        "mixed_frac": mixed["mixed_frac"] if mixed else None,
+        "mixed": mixed if mixed else {"note": mixed_note},
         "winograd_transforms": {"ms_per_step": ms[3], "bytes_per_step": work_[3], "launches_per_step": int(launches[3]),
                                 "GB_per_s": (work_[3] / (ms[3] * 1e-3) / 1e9) if ms[3] > 0 else None}}
+    # both floors of the phase stage: HBM (algorithmic bytes at 8 TB/s) and the matrix pipes (pyramid_frame_kernel: 4 344
+    # v_mfma_f32_16x16x4_f32 = 8.9 MFLOP per frame) -- the MFMA floor is the higher one
+    ph_floor_hbm = (work_[1] + work_[2]) / (PEAK_HBM_GBS * 1e9) * 1e3
+    ph_floor_mfma = n_frames * 4344 * 2048.0 / (PEAK_FP32_MFMA_TFLOPS * 1e12) * 1e3
     result["roofline_phase"] = {"bound": "hbm", "kernel": "pyramid_frame_kernel + phase_window2_kernel<48|24> (all phase-stage launches of one step)",
                                 "achieved": phase_gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": phase_gbs / PEAK_HBM_GBS,
+                                "floor_hbm_ms": ph_floor_hbm, "floor_mfma_ms": ph_floor_mfma,
+                                "limiting_floor": "mfma" if ph_floor_mfma > ph_floor_hbm else "hbm",
+                                "frac_of_limiting_floor": max(ph_floor_hbm, ph_floor_mfma) / phase_ms,
                                 "traffic": ptraffic, "traffic_file": ptraffic_file, "bytes_per_step": work_[1] + work_[2], "ms_per_step": phase_ms,
                                 "ms_pyramid": ms[1], "ms_window": ms[2]}
 

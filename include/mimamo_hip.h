@@ -259,10 +259,12 @@ int mm_preproc_forward(mm_preproc_t* h, const uint8_t* frames, int64_t n, float*
  * Measurement hook (bench.py roofline leg; not part of the reference surface).  Between begin and
  * end every kernel launch is bracketed by hipEvents on its own stream.  Categories: 0 conv/GEMM
  * engine (work = FLOPs executed on the matrix cores, 2*M*K*Cout per problem), 1 pyramid kernel, 2 phase-window kernel
- * (work = algorithmic HBM bytes: frame in / phase planes out), 3 Winograd input/output transforms (work = bytes moved).  Arrays hold MM_PROF_CATEGORIES entries.
+ * (work = algorithmic HBM bytes: frame in / phase planes out), 3 Winograd input/output transforms (work = bytes moved), 4 the other
+ * data-movement kernels (preprocessing, max-pool, average pools, layout conversions, GRU gates; work = algorithmic bytes).  Arrays hold
+ * MM_PROF_CATEGORIES entries.
  * mm_profile_end synchronises the device.
  * ------------------------------------------------------------------------------------- */
-#define MM_PROF_CATEGORIES 4
+#define MM_PROF_CATEGORIES 5
 int mm_profile_begin(void);
 int mm_profile_end(double* ms, double* work, int64_t* launches);
 

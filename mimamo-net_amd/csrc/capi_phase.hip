@@ -152,9 +152,12 @@ int mm_phase_diff_frames(mm_pyramid_t* h, const float* frames, int64_t n, const 
     // once per unique frame: pyramid, atan2 / magnitude, the frame-only blurs (B, R) -- one kernel; then one blur per (window, frame)
     int rc = mm::launch_pyramid_frames(h, frames, n, f1, f2, s);
     if (rc != MM_OK) return rc;
-    mm::prof_before(2, (double)J * 2 * 12 * (S * S + (S / 2) * (S / 2)) * 4, s);   // algorithmic write: 24 + 24 difference planes
+    mm::prof_before(2, (double)J * 2 * 12 * (S * S) * 4, s, "phase_window2<48>");               // algorithmic write: 24 difference planes
     rc = mm::launch_phase_window2(f1, ids, n, J, (int)S, out0, out0_nhwc, out0_cstride, out0_coffset, s);
-    if (rc == MM_OK) rc = mm::launch_phase_window2(f2, ids, n, J, (int)S / 2, out1, out1_nhwc, out1_cstride, out1_coffset, s);
+    mm::prof_after(2, s);
+    if (rc != MM_OK) return rc;
+    mm::prof_before(2, (double)J * 2 * 12 * ((S / 2) * (S / 2)) * 4, s, "phase_window2<24>");
+    rc = mm::launch_phase_window2(f2, ids, n, J, (int)S / 2, out1, out1_nhwc, out1_cstride, out1_coffset, s);
     mm::prof_after(2, s);
     return rc;
 }

@@ -63,6 +63,9 @@ int wino_gemm_output_fused(const float* V, const float* U, const float* bias, fl
 int wino_gemm_output_fused_inc(const float* V, const float* U, const float* bias, const float* W2, const float* bias2, const float* res,
                                float* out, int B, int H, int W, int Cin, int Cout, int C2, int relu, hipStream_t s);
 bool wino_fused_inc_supported(int64_t ntile, int Cin, int Cout, int C2);
+// ... and with increase conv + stride-1 projection shortcut as one contraction over [relu(conv3x3) ; x] (conv2_x block 1): W2 [C2][128]
+int wino_gemm_output_fused_incproj(const float* V, const float* U, const float* bias, const float* W2, const float* bias2, const float* x,
+                                   float* out, int B, int H, int W, int Cin, int Cout, int C2, int relu, hipStream_t s);
 // whether wino_gemm_output_fused takes the shape (channel granularity, 32-bit offsets inside a position plane)
 bool wino_fused_supported(int64_t ntile, int Cin, int Cout);
 

@@ -55,7 +55,9 @@ nchw3_to_bordered_nhwc3_kernel(const float* __restrict__ in, float* __restrict__
 int nchw3_to_bordered_nhwc3(const float* in, float* out, int64_t N, int S, int pad, hipStream_t s) {
     if (N <= 0) return MM_OK;
     const int64_t total = N * (int64_t)(S + 2 * pad) * (S + 2 * pad);
+    prof_before(4, (double)N * 4.0 * (3.0 * S * S + 3.0 * (S + 2 * pad) * (S + 2 * pad)), s, "nchw3_to_bordered_nhwc3");
     hipLaunchKernelGGL(nchw3_to_bordered_nhwc3_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, in, out, total, S, pad);
+    prof_after(4, s);
     MM_LAUNCH_CHECK();
     return MM_OK;
 }
@@ -65,13 +67,17 @@ int nchw_to_nhwc(const float* in, float* out, int64_t N, int C, int HW, int cstr
     if (cpad < C) cpad = C;
     if (C == 3 && cpad == 4 && cstride == 4 && coff == 0) {
         const int64_t total = N * HW;
+        prof_before(4, (double)total * 4.0 * 7.0, s, "nchw3_to_nhwc4");
         hipLaunchKernelGGL(nchw3_to_nhwc4_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, in,
                            reinterpret_cast<float4*>(out), total, HW);
+        prof_after(4, s);
         MM_LAUNCH_CHECK();
         return MM_OK;
     }
     dim3 grid((HW + 31) / 32, (cpad + 31) / 32, (unsigned)N);
+    prof_before(4, (double)N * HW * 4.0 * (C + cpad), s, "nchw_to_nhwc");
     hipLaunchKernelGGL(nchw_to_nhwc_kernel, grid, dim3(256), 0, s, in, out, C, HW, cstride, coff, cpad);
+    prof_after(4, s);
     MM_LAUNCH_CHECK();
     return MM_OK;
 }
@@ -105,7 +111,9 @@ int maxpool3x3s2(const float* in, float* out, int64_t N, int H, int W, int C, in
     if (C % 4) return MM_ERR_INVALID_ARG;
     const int64_t total4 = N * Ho * Wo * (C / 4);
     if (total4 <= 0) return MM_OK;
+    prof_before(4, (double)N * C * 4.0 * ((double)H * W + (double)Ho * Wo), s, "maxpool3x3s2");   // every input read once, output written
     hipLaunchKernelGGL(maxpool_kernel, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, s, in, out, total4, H, W, C / 4, Ho, Wo);
+    prof_after(4, s);
     MM_LAUNCH_CHECK();
     return MM_OK;
 }
@@ -127,7 +135,9 @@ avgpool_kernel(const float* __restrict__ in, float* __restrict__ out, int64_t to
 int avgpool_hw(const float* in, float* out, int64_t N, int HW, int C, int out_cstride, int out_coff, int relu, hipStream_t s) {
     const int64_t total = N * C;
     if (total <= 0) return MM_OK;
+    prof_before(4, (double)total * 4.0 * (HW + 1), s, "avgpool");
     hipLaunchKernelGGL(avgpool_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, in, out, total, HW, C, out_cstride, out_coff, relu);
+    prof_after(4, s);
     MM_LAUNCH_CHECK();
     return MM_OK;
 }
@@ -163,8 +173,10 @@ int gru_gates(const float* gi, int gi_stride, int gi_off, const float* gh, const
               int hp_stride, int hp_off, float* h_out, int out_stride, int out_off, int64_t Bt, int H, hipStream_t s) {
     const int64_t total = Bt * H;
     if (total <= 0) return MM_OK;
+    prof_before(4, (double)total * 4.0 * (gh ? 8.0 : 4.0), s, "gru_gates");
     hipLaunchKernelGGL(gru_gates_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, gi, gi_stride, gi_off, gh, bhh,
                        h_prev, hp_stride, hp_off, h_out, out_stride, out_off, total, H);
+    prof_after(4, s);
     MM_LAUNCH_CHECK();
     return MM_OK;
 }

@@ -22,6 +22,7 @@ struct Layer {
     float* wino_u4 = nullptr;  // [36][cout][cin] F(4x4,3x3)-domain weights
     int cin = 0, cin_p = 0, cout = 0, k = 1, stride = 1, pad = 0, K = 0, Kpad = 0, relu = 0, korder = 0;
     int wino_cin = 0;          // channels of the Winograd-domain weights: cin, or cin padded with zero columns (wino_pad)
+    int tile = 0;              // conv engine tile for this layer (0 = automatic; measurement knob MM_STEM_TILE for the stem)
 };
 
 struct DeviceArena {
@@ -189,7 +190,7 @@ static int run_layer(const Layer& L, const float* in, int B, int H, int W, int i
     p.Cout = L.cout; p.out_cstride = out_cstride; p.out_coff = out_coff;
     p.res_cstride = res_cstride; p.res_coff = 0;
     p.kh = L.k; p.kw = L.k; p.stride = L.stride; p.pad = L.pad;
-    p.K = L.K; p.Kpad = L.Kpad; p.relu = L.relu; p.Cin_real = L.cin; p.korder = L.korder;
+    p.K = L.K; p.Kpad = L.Kpad; p.relu = L.relu; p.Cin_real = L.cin; p.korder = L.korder; p.force_tile = L.tile;
     if (Ho_) *Ho_ = p.Ho;
     if (Wo_) *Wo_ = p.Wo;
     return conv_forward(p, s);
@@ -216,8 +217,10 @@ static int g_wino_fused_shape = 0;   // measurement knob (MM_WINO_FUSED_SHAPE): 
 // inc / inc_res / inc_out (optional, fused form only): the residual block's increase layer applied inside the fused kernel --
 // inc_out [B,H,W,inc->cout] = relu(inc(relu(L(in))) + inc_res); `out` is then not written.  Returns MM_ERR_UNSUPPORTED (before
 // anything is launched) when the shape is not the one wino_fused.hip's INC instantiation takes.
+// inc_two_src: `inc` is a make_layer_dual layer (K = L.cout + L.cout: increase | stride-1 projection) and inc_res the block input x
+// [B,H,W,L.cout] -- inc_out = relu(inc([relu(L(in)); x])), no residual.
 static int run_layer_wino(const Layer& L, const float* in, int B, int H, int W, float* out, float* V, float* M, int m, hipStream_t s,
-                          const Layer* inc = nullptr, const float* inc_res = nullptr, float* inc_out = nullptr) {
+                          const Layer* inc = nullptr, const float* inc_res = nullptr, float* inc_out = nullptr, bool inc_two_src = false) {
     const int mt = m == 5 ? 4 : m;
     const int TH = (H + mt - 1) / mt, TW = (W + mt - 1) / mt, npos = (mt + 2) * (mt + 2);
     const int64_t ntile = (int64_t)B * TH * TW;
@@ -228,11 +231,14 @@ static int run_layer_wino(const Layer& L, const float* in, int B, int H, int W, 
     if (wc != L.cin_p && m != 4) return MM_ERR_UNSUPPORTED;
     // no plane set for the three-kernel form and the fused kernel declines the shape: say so before transforming anything
     if (!M && !(fused && wino_fused_supported(ntile, wc, L.cout))) return MM_ERR_UNSUPPORTED;
-    if (inc && !(fused && inc->k == 1 && inc->stride == 1 && inc->Kpad == L.cout && inc->korder == 0 && inc->relu && !inc->ps &&
-                 wino_fused_inc_supported(ntile, wc, L.cout, inc->cout)))
+    if (inc && !(fused && inc->k == 1 && inc->stride == 1 && inc->Kpad == (inc_two_src ? 2 : 1) * L.cout && inc->korder == 0 && inc->relu &&
+                 !inc->ps && wino_fused_inc_supported(ntile, wc, L.cout, inc->cout)))
         return MM_ERR_UNSUPPORTED;
     int rc = wino_input_transform(in, V, B, H, W, wc, m, s, L.cin_p);
     if (rc != MM_OK) return rc;
+    if (inc && inc_two_src)
+        return wino_gemm_output_fused_incproj(V, L.wino_u4, L.bias, inc->w, inc->bias, inc_res, inc_out, B, H, W, wc, L.cout, inc->cout,
+                                              L.relu, s);
     if (inc)
         return wino_gemm_output_fused_inc(V, L.wino_u4, L.bias, inc->w, inc->bias, inc_res, inc_out, B, H, W, wc, L.cout, inc->cout,
                                           L.relu, s);
@@ -399,7 +405,7 @@ int mm_resnet50_create(mm_resnet50_t** out, const float* blob, int64_t n_floats,
         const char* fp = getenv("MM_FUSE_PROJ");   // measurement knob: 0 = projection shortcut as its own launch + residual read
         h->fuse_proj = fp ? atoi(fp) : 1;
         const char* fi = getenv("MM_FUSE_INC");    // measurement knob: 0 = 3x3 and increase conv as separate launches (the parity twin)
-        h->fuse_inc = fi ? atoi(fi) : 1;
+        h->fuse_inc = fi ? atoi(fi) : 2;           // 1 = blocks 2, 3 only; 2 (default) = also block 1 (increase | projection over two K sources)
     }
     auto conv_bn = [&](Layer& L, int cout, int cin, int k, int stride, int pad, int relu) {
         const float* w = p;
@@ -414,6 +420,10 @@ int mm_resnet50_create(mm_resnet50_t** out, const float* blob, int64_t n_floats,
         rc = make_layer(h->arena, h->stem3, w, nullptr, 64, 3, 7, 2, 0, 1, &bn, nullptr, bn_eps, false, true);
     }
     conv_bn(h->stem, 64, 3, 7, 2, 3, 1);
+    if (const char* st = getenv("MM_STEM_TILE")) {   // measurement knob: 1 = 128x128, 2 = 128x64 (automatic choice), 3 = 64x64, 4 = 256x64
+        const int t = atoi(st);
+        if (t >= 0 && t <= 4) h->stem.tile = h->stem3.tile = t;
+    }
     int cin = 64;
     for (auto& st : kStages)
         for (int b = 0; b < st[0]; ++b) {
@@ -545,6 +555,10 @@ int mm_resnet50_forward(mm_resnet50_t* h, const float* images, int nchw, int64_t
             if (wm_ == 5 && h->fuse_inc && !Bk.has_proj) {
                 // conv2_x blocks 2, 3 (Cin = Cout = 64 -> 256): 3x3 + increase + residual + ReLU in one kernel
                 rc = run_layer_wino(Bk.conv3, y1, B, H1, W1, nullptr, wv, nullptr, 5, s, &Bk.increase, x, o);
+                inc_done = rc == MM_OK;
+            } else if (wm_ == 5 && h->fuse_inc >= 2 && dual && Bk.proj_stride == 1 && C == Bk.conv3.cout && H1 == H && W1 == W) {
+                // conv2_x block 1: 3x3 + (increase | projection of the block input) + ReLU in one kernel
+                rc = run_layer_wino(Bk.conv3, y1, B, H1, W1, nullptr, wv, nullptr, 5, s, &Bk.inc_proj, x, o, true);
                 inc_done = rc == MM_OK;
             }
             if (rc == MM_ERR_UNSUPPORTED) rc = run_layer_wino(Bk.conv3, y1, B, H1, W1, y2, wv, wm, wm_, s);

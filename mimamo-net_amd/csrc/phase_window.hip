@@ -232,7 +232,7 @@ int launch_phase_window(const float* coeff, const int32_t* ids, int64_t img_stri
                         int W, float* out, int out_nhwc, int out_cstride, int out_coffset, int polar, hipStream_t stream) {
     if (J <= 0) return MM_OK;
     const dim3 grid((unsigned)(2 * J));
-    prof_before(2, (double)J * 2 * (P - 1) * W * W * 4, stream);  // algorithmic write: 24 phase-difference planes
+    prof_before(2, (double)J * 2 * (P - 1) * W * W * 4, stream, "phase_window");  // algorithmic write: 24 phase-difference planes
 #define MM_WIN(WW, PP)                                                                                                  \
     hipLaunchKernelGGL((phase_window_kernel<WW, PP>), grid, dim3(WinCfg<WW>::NTHREADS), 0, stream, coeff, ids, img_stride, \
                        band_stride, out, out_nhwc, out_cstride, out_coffset)

@@ -369,8 +369,10 @@ int mm_preproc_forward(mm_preproc_t* h, const uint8_t* frames, int64_t n, float*
         if (lds > 64 * 1024)
             MM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(mm::preproc_gray_kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        mm::prof_before(4, (double)n * (3.0 * h->in_size * h->in_size + 4.0 * h->gray_size * h->gray_size), s, "preproc_gray");
         hipLaunchKernelGGL(mm::preproc_gray_kernel, dim3((unsigned)n), dim3(256), lds, s, frames, h->in_size, h->gray_size,
                            h->lan.ksize, h->d_lan_bounds, h->d_lan_kk, gray_out);
+        mm::prof_after(4, s);
         MM_LAUNCH_CHECK();
     }
     if (rgb_out && rgb_nchw == 2) {
@@ -380,13 +382,17 @@ int mm_preproc_forward(mm_preproc_t* h, const uint8_t* frames, int64_t n, float*
         if (max_in <= 0 || max_in > mm::RGB_MAX_IN || h->bil.ksize > 4 || (int64_t)max_in * h->crop * 3 > 60 * 1024)
             return MM_ERR_UNSUPPORTED;   // (a down-scaling resize: not the reference's 112 -> 256)
         dim3 grid((unsigned)n, (unsigned)((h->crop + mm::RGB_ROWS - 1) / mm::RGB_ROWS));
+        mm::prof_before(4, (double)n * (3.0 * h->in_size * h->in_size + 12.0 * (h->crop + 6) * (h->crop + 6)), s, "preproc_rgb3");
         hipLaunchKernelGGL(mm::preproc_rgb3_kernel, grid, dim3(256), max_in * h->crop * 3, s, frames, h->in_size, h->resize, h->crop,
                            h->bil.ksize, h->d_bil_bounds, h->d_bil_kk, h->mean[0], h->mean[1], h->mean[2], rgb_out);
+        mm::prof_after(4, s);
         MM_LAUNCH_CHECK();
     } else if (rgb_out) {
         dim3 grid((unsigned)n, (unsigned)((h->crop + 15) / 16));
+        mm::prof_before(4, (double)n * (3.0 * h->in_size * h->in_size + (rgb_nchw ? 12.0 : 16.0) * h->crop * h->crop), s, "preproc_rgb");
         hipLaunchKernelGGL(mm::preproc_rgb_kernel, grid, dim3(256), 0, s, frames, h->in_size, h->resize, h->crop, h->bil.ksize,
                            h->d_bil_bounds, h->d_bil_kk, h->mean[0], h->mean[1], h->mean[2], rgb_out, rgb_nchw);
+        mm::prof_after(4, s);
         MM_LAUNCH_CHECK();
     }
     return MM_OK;

@@ -284,7 +284,7 @@ int launch_pyramid(const mm_pyramid* h, const float* frames, int64_t n, int64_t 
                                lds_bytes));
     int64_t grid = n;
     if (grid > 1024) grid = 1024;  // 256 CUs x 1 resident workgroup; the rest grid-strides
-    prof_before(1, (double)n * (S * S * 4), stream);  // algorithmic read of the stage: one fp32 frame
+    prof_before(1, (double)n * (S * S * 4), stream, "pyramid");  // algorithmic read of the stage: one fp32 frame
     hipLaunchKernelGGL(pyramid_kernel, dim3((unsigned)grid), dim3(NT), lds_bytes, stream, h->d_tables, frames, n,
                        group > 0 ? group : n, c1, gs1, is1, bs1, c2, gs2, is2, bs2, polar);
     prof_after(1, stream);

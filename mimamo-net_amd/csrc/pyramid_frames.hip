@@ -422,7 +422,7 @@ int launch_pyramid_frames(const mm_pyramid* h, const float* frames, int64_t n, f
     static const int grid_cap = getenv("MM_PF_GRID") ? atoi(getenv("MM_PF_GRID")) : 2048;
     int64_t grid = n;
     if (grid > grid_cap) grid = grid_cap;   // 256 CUs x 2 resident workgroups x 4 rounds; the rest grid-strides (tables stay in LDS)
-    prof_before(1, (double)n * (pyr::S * pyr::S * 4), stream);   // algorithmic read of the stage: one fp32 frame
+    prof_before(1, (double)n * (pyr::S * pyr::S * 4), stream, "pyramid_frame");   // algorithmic read of the stage: one fp32 frame
     hipLaunchKernelGGL(pf::pyramid_frame_kernel, dim3((unsigned)grid), dim3(pf::NT), lds_bytes, stream, h->d_tables, frames, n, f1, f2, ablate);
     prof_after(1, stream);
     MM_LAUNCH_CHECK();

@@ -39,7 +39,7 @@ struct WinoFusedParams {
     // INC instantiation only: the residual block's 1x1 increase conv applied to this layer's output before it leaves the CU
     const float* w2;     // [C2][Cout] BN-folded increase weights (Cout == 64: the workgroup owns every channel of its pixels)
     const float* bias2;  // [C2]
-    const float* res;    // residual, NHWC [B][H][W][C2]
+    const float* res;    // INC 1: residual, NHWC [B][H][W][C2].  INC 2: the block input x, NHWC [B][H][W][Cout] -- the second K source
     int C2;              // 256
 };
 
@@ -51,7 +51,7 @@ static constexpr float kAtHost[4][6] = {{1, 1, 1, 1, 1, 0}, {0, 1, -1, 2, -2, 0}
 // from the accumulator registers -- in that layout they ARE the B operand of the second MFMA -- adds the residual, applies the ReLU
 // and writes the block's 256-channel output: the 64-channel tensor between the 3x3 and the increase conv (1.6 MB per frame written
 // and re-read) never exists, and the 49 %-busy K = 64 GEMM launch disappears.
-template <int NBUF, int WGM, bool INC = false>
+template <int NBUF, int WGM, int INC = 0>
 __global__ void __launch_bounds__(WGM * 128) __attribute__((amdgpu_waves_per_eu(2, 2)))
 wino_fused_kernel(const WinoFusedParams p) {
     // WGM = 4: eight waves, 64 tiles x 64 channels, one workgroup per CU; WGM = 2: four waves, 32 tiles x 64 channels, two
@@ -278,7 +278,120 @@ wino_fused_kernel(const WinoFusedParams p) {
     update_y(5);
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");   // tail loads drained, everyone done with the ring
 
-    if constexpr (INC) {
+    if constexpr (INC == 2) {
+        // ---- first block of conv2_x: increase conv + projection shortcut as ONE contraction over K = 64 (this layer's output) + 64 (the
+        // block input x at the same pixels): out = relu( [W2a | W2b] [relu(Y + bias); x] + bias2 ), W2 = [256][128] (make_layer_dual).
+        // The matrix is 128 KB: two passes over its row halves (128 output channels each, 64 KB in the dead ring); wave (wm, wn)
+        // produces channels [128 pass + 64 wn, + 64) of its 16 tiles.  The x operand needs no staging at all: in the transposed
+        // layout a lane's B values are 4 consecutive channels of its tile's pixel -- one 16-byte global load.
+        static_assert(WGM == 2 && NBUF == 3, "INC is built for the four-wave workgroup");
+        constexpr int K2 = 2 * KS;                                     // 128
+        constexpr int W2_FLOATS = 128 * K2;                            // one row half
+        float* xb = lds + W2_FLOATS;
+        float* b2s = xb + 2048;
+        const int x_own = (wave * 8 + lg) * 64 + l16 * 4, x_par = ((wave ^ 1) * 8 + lg) * 64 + l16 * 4;
+        f32x4v b1[2];
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb) {
+            const float4 t = p.bias ? *reinterpret_cast<const float4*>(p.bias + wn * 32 + cb * 16 + 4 * lg) : float4{0.f, 0.f, 0.f, 0.f};
+            b1[cb] = f32x4v{t.x, t.y, t.z, t.w};
+        }
+        const int tpi = p.TH * p.TW;
+        const int t = m_base + wm * 16 + l16;
+        const bool tok = t < p.ntile;
+        const int tt = tok ? t : 0;
+        const int bimg = tt / tpi, rem = tt - bimg * tpi;
+        const int ty = rem / p.TW, tx = rem - ty * p.TW;
+        const int64_t pix0 = ((int64_t)bimg * p.H + 4 * ty) * p.W + 4 * tx;
+        const float* xbase = p.res + pix0 * KS + 4 * lg;               // x: 64 channels per pixel
+        // A-operand offsets (row stride 128 floats, 32 k-quads per row, quad q of row r in slot q ^ (r & 15)): sidx 0-1 own channel
+        // blocks, 2-3 the partner's, 4-7 the four 16-channel blocks of x
+        int wa[8];
+#pragma unroll
+        for (int sidx = 0; sidx < 8; ++sidx) {
+            const int qd = sidx < 4 ? ((sidx < 2 ? wn : 1 - wn) * 8 + (sidx & 1) * 4 + lg) : 16 + (sidx - 4) * 4 + lg;
+            wa[sidx] = (wn * 64 + l16) * K2 + ((qd ^ l16) << 2);
+        }
+        b2s[tid] = p.bias2[tid];
+#pragma unroll
+        for (int pp = 0; pp < 4; ++pp)
+#pragma unroll
+            for (int qq = 0; qq < 4; ++qq)
+#pragma unroll
+                for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float v = Y[pp][qq][cb][e] + b1[cb][e];
+                        Y[pp][qq][cb][e] = p.relu ? fmaxf(v, 0.f) : v;
+                    }
+        auto x_rows = [&](f32x4v (&r)[4], int pos) {
+            const int pp = pos >> 2, qq = pos & 3;
+            const bool pok = tok && 4 * ty + pp < p.H && 4 * tx + qq < p.W;
+            const float* xp = pok ? xbase + ((int64_t)pp * p.W + qq) * KS : p.res + 4 * lg;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) r[j] = *reinterpret_cast<const f32x4v*>(xp + j * 16);
+        };
+        for (int pass = 0; pass < 2; ++pass) {
+            // (second pass: every wave is past its last read of the first half)
+            // (vmcnt(0): the first pass's stores are drained, so the counted wait below sees only this pass's loads)
+            if (pass) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            {
+                const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.w2) + (int64_t)pass * W2_FLOATS, 0,
+                                                                                    (unsigned)(W2_FLOATS * 4), 0x00020000);
+#pragma unroll
+                for (int it = 0; it < 128 / (2 * NW); ++it) {
+                    const int row = (it * NW + wave) * 2 + (lane >> 5);
+                    const unsigned voff = (unsigned)(row * K2 + (((lane & 31) ^ (row & 15)) << 2)) * 4u;
+                    dma1(rw, voff, lds0 + (unsigned)((it * NW + wave) * 1024));
+                }
+            }
+            const int c0 = pass * 128 + wn * 64 + 4 * lg;               // first output channel of this lane in this pass
+            float* obase = p.out + pix0 * p.C2 + c0;
+            f32x4v xs[2][4], Pr[2];
+            x_rows(xs[0], 0);
+            asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory");   // the matrix half landed (the 4 x loads may still fly)
+#pragma unroll
+            for (int pos = 0; pos < 16; ++pos) {
+                const int pp = pos >> 2, qq = pos & 3;
+                if (pos) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#pragma unroll
+                for (int cb = 0; cb < 2; ++cb) *reinterpret_cast<f32x4v*>(xb + x_own + cb * 256) = Y[pp][qq][cb];
+                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#pragma unroll
+                for (int cb = 0; cb < 2; ++cb) Pr[cb] = *reinterpret_cast<const f32x4v*>(xb + x_par + cb * 256);
+                if (pos + 1 < 16) x_rows(xs[(pos + 1) & 1], pos + 1);
+                f32x4v acc[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[j] = *reinterpret_cast<const f32x4v*>(b2s + c0 + j * 16);
+#pragma unroll
+                for (int sidx = 0; sidx < 8; ++sidx) {
+                    const f32x4v Bv = sidx < 2 ? Y[pp][qq][sidx & 1] : sidx < 4 ? Pr[sidx & 1] : xs[pos & 1][sidx - 4];
+                    float4 w4[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) w4[j] = *reinterpret_cast<const float4*>(lds + wa[sidx] + (j * 16) * K2);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(w4[j].x, Bv[0], acc[j], 0, 0, 0);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(w4[j].y, Bv[1], acc[j], 0, 0, 0);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(w4[j].z, Bv[2], acc[j], 0, 0, 0);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(w4[j].w, Bv[3], acc[j], 0, 0, 0);
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[j][e] = fmaxf(acc[j][e], 0.f);
+                if (tok && 4 * ty + pp < p.H && 4 * tx + qq < p.W) {
+                    float* op = obase + ((int64_t)pp * p.W + qq) * p.C2;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) __builtin_nontemporal_store(acc[j], reinterpret_cast<f32x4v*>(op + j * 16));
+                }
+            }
+        }
+        return;
+    }
+    if constexpr (INC == 1) {
         // ---- second GEMM: out[n2][pixel] = relu( sum_c W2[n2][c] * relu(Y + bias)[c][pixel] + bias2[n2] + res[pixel][n2] ), C2 = 256.
         // The dead operand ring takes the whole increase matrix (256 rows x 256 B, same XOR-swizzled rows as the slabs) plus an 8 KB
         // exchange area.  A wave holds 32 of the 64 channels of its 16 tiles; the wave with the other 32 (same tiles: wave ^ 1) gets a
@@ -323,11 +436,26 @@ wino_fused_kernel(const WinoFusedParams p) {
             const int qd = ((sidx < 2 ? wn : 1 - wn) * 8 + (sidx & 1) * 4 + lg) ^ l16;
             wa[sidx] = (wn * 128 + l16) * KS + (qd << 2);
         }
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");   // W2 landed
+        // bias2 -> LDS behind the exchange area (1 KB): read back per block as the accumulators' initial value
+        float* b2s = xb + 2048;
+        b2s[tid] = p.bias2[tid];                                          // 256 threads, C2 == 256
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");   // W2 and bias2 landed
+        // 32 half-position steps (position = (pp, qq), half = 64 of this wave's 128 output channels).  The residual rows of step
+        // s + 1 are requested before the MFMAs of step s (their HBM latency runs under 64 MFMAs and, across a position change,
+        // under the exchange barriers).
+        auto res_rows = [&](f32x4v (&r)[4], int step) {
+            const int pp = step >> 3, qq = (step >> 1) & 3, h = step & 1;
+            const bool pok = tok && 4 * ty + pp < p.H && 4 * tx + qq < p.W;
+            const float* rp = pok ? rbase + ((int64_t)pp * p.W + qq) * p.C2 : p.res + c0;   // clipped pixel: a valid address, nothing stored
 #pragma unroll
-        for (int pp = 0; pp < 4; ++pp) {
+            for (int j = 0; j < 4; ++j) r[j] = *reinterpret_cast<const f32x4v*>(rp + h * 64 + j * 16);
+        };
+        f32x4v rs[2][4], Pr[2];
+        res_rows(rs[0], 0);
 #pragma unroll
-            for (int qq = 0; qq < 4; ++qq) {
+        for (int step = 0; step < 32; ++step) {
+            const int pp = step >> 3, qq = (step >> 1) & 3, h = step & 1;
+            if (h == 0) {
 #pragma unroll
                 for (int cb = 0; cb < 2; ++cb)
 #pragma unroll
@@ -335,53 +463,42 @@ wino_fused_kernel(const WinoFusedParams p) {
                         const float v = Y[pp][qq][cb][e] + b1[cb][e];
                         Y[pp][qq][cb][e] = p.relu ? fmaxf(v, 0.f) : v;
                     }
-                if (pp | qq) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // the previous position's copies have been read
+                if (step) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // the previous position's copies have been read
 #pragma unroll
                 for (int cb = 0; cb < 2; ++cb) *reinterpret_cast<f32x4v*>(xb + x_own + cb * 256) = Y[pp][qq][cb];
                 asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-                f32x4v Pr[2];
 #pragma unroll
                 for (int cb = 0; cb < 2; ++cb) Pr[cb] = *reinterpret_cast<const f32x4v*>(xb + x_par + cb * 256);
-                const bool pok = tok && 4 * ty + pp < p.H && 4 * tx + qq < p.W;
-                const int64_t poff = ((int64_t)pp * p.W + qq) * p.C2;
-                const float* rp = pok ? rbase + poff : p.res + c0;       // a clipped pixel reads a valid address and stores nothing
+            }
+            if (step + 1 < 32) res_rows(rs[(step + 1) & 1], step + 1);
+            f32x4v acc[4];
 #pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    f32x4v rs[4], bs[4], acc[4];
+            for (int j = 0; j < 4; ++j) acc[j] = *reinterpret_cast<const f32x4v*>(b2s + c0 + h * 64 + j * 16);
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const int n2 = h * 64 + j * 16;
-                        rs[j] = *reinterpret_cast<const f32x4v*>(rp + n2);
-                        bs[j] = *reinterpret_cast<const f32x4v*>(p.bias2 + c0 + n2);
-                        acc[j] = f32x4v{0.f, 0.f, 0.f, 0.f};
-                    }
+            for (int sidx = 0; sidx < 4; ++sidx) {
+                const f32x4v Bv = sidx < 2 ? Y[pp][qq][sidx & 1] : Pr[sidx & 1];
+                float4 w4[4];
 #pragma unroll
-                    for (int sidx = 0; sidx < 4; ++sidx) {
-                        const f32x4v Bv = sidx < 2 ? Y[pp][qq][sidx & 1] : Pr[sidx & 1];
-                        float4 w4[4];
+                for (int j = 0; j < 4; ++j) w4[j] = *reinterpret_cast<const float4*>(lds + wa[sidx] + (h * 64 + j * 16) * KS);
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) w4[j] = *reinterpret_cast<const float4*>(lds + wa[sidx] + (h * 64 + j * 16) * KS);
+                for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(w4[j].x, Bv[0], acc[j], 0, 0, 0);
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(w4[j].x, Bv[0], acc[j], 0, 0, 0);
+                for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(w4[j].y, Bv[1], acc[j], 0, 0, 0);
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(w4[j].y, Bv[1], acc[j], 0, 0, 0);
+                for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(w4[j].z, Bv[2], acc[j], 0, 0, 0);
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(w4[j].z, Bv[2], acc[j], 0, 0, 0);
+                for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(w4[j].w, Bv[3], acc[j], 0, 0, 0);
+            }
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(w4[j].w, Bv[3], acc[j], 0, 0, 0);
-                    }
+            for (int j = 0; j < 4; ++j) {
+                acc[j] = acc[j] + rs[step & 1][j];
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        acc[j] = acc[j] + bs[j] + rs[j];
+                for (int e = 0; e < 4; ++e) acc[j][e] = fmaxf(acc[j][e], 0.f);
+            }
+            if (tok && 4 * ty + pp < p.H && 4 * tx + qq < p.W) {
+                float* op = obase + ((int64_t)pp * p.W + qq) * p.C2 + h * 64;
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) acc[j][e] = fmaxf(acc[j][e], 0.f);
-                    }
-                    if (pok) {
-#pragma unroll
-                        for (int j = 0; j < 4; ++j)
-                            __builtin_nontemporal_store(acc[j], reinterpret_cast<f32x4v*>(obase + poff + h * 64 + j * 16));
-                    }
-                }
+                for (int j = 0; j < 4; ++j) __builtin_nontemporal_store(acc[j], reinterpret_cast<f32x4v*>(op + j * 16));
             }
         }
         return;
@@ -436,11 +553,13 @@ wino_fused_kernel(const WinoFusedParams p) {
     }
 }
 
-template <int NBUF, int WGM, bool INC = false>
+template <int NBUF, int WGM, int INC = 0>
 static int launch_fused(WinoFusedParams p, hipStream_t s) {
     constexpr int BM = 16 * WGM;
-    constexpr int LDS_BYTES = NBUF * (BM + 64) * 64 * 4;
-    static_assert(!INC || LDS_BYTES >= (256 * 64 + 2048) * 4, "INC: increase matrix + exchange area live in the dead ring");
+    // INC: the increase matrix (64 KB) + exchange area (8 KB) take the dead operand ring, bias2 (1 KB) sits behind it: 73 KB, two
+    // workgroups per CU still fit the 160 KB
+    constexpr int LDS_BYTES = INC ? (256 * 64 + 2048 + 256) * 4 : NBUF * (BM + 64) * 64 * 4;
+    static_assert(!INC || LDS_BYTES >= NBUF * (BM + 64) * 64 * 4, "the ring must fit too");
     static bool attr_set[16] = {};
     int dev = 0;
     (void)hipGetDevice(&dev);
@@ -456,9 +575,9 @@ static int launch_fused(WinoFusedParams p, hipStream_t s) {
     if (blocks <= 0 || blocks > 0x7fffffff) return MM_ERR_INVALID_ARG;
     if (prof_enabled()) {
         char tag[64];
-        snprintf(tag, sizeof(tag), "wino-fused%s M=%d K=%d N=%d t%dx64 b36", INC ? "+inc256" : "", p.ntile, p.K, p.Cout, BM);
+        snprintf(tag, sizeof(tag), "wino-fused%s M=%d K=%d N=%d t%dx64 b36", INC == 2 ? "+incproj256" : INC ? "+inc256" : "", p.ntile, p.K, p.Cout, BM);
         double fl = 2.0 * 36.0 * (double)p.ntile * (double)p.K * (double)p.Cout;
-        if (INC) fl += 2.0 * (double)p.B * p.H * p.W * (double)p.Cout * (double)p.C2;
+        if (INC) fl += 2.0 * (double)p.B * p.H * p.W * (double)(INC == 2 ? 2 * p.Cout : p.Cout) * (double)p.C2;
         prof_before(0, fl, s, tag);
     }
     hipLaunchKernelGGL((wino_fused_kernel<NBUF, WGM, INC>), dim3((unsigned)blocks), dim3(WGM * 128), LDS_BYTES, s, p);
@@ -507,7 +626,24 @@ int wino_gemm_output_fused_inc(const float* V, const float* U, const float* bias
     if (!wino_fused_inc_supported(ntile, Cin, Cout, C2)) return MM_ERR_UNSUPPORTED;
     if (ntile <= 0) return MM_OK;
     p.ntile = (int)ntile; p.K = Cin; p.Cout = Cout; p.B = B; p.H = H; p.W = W; p.relu = relu; p.tiles_n = 0;
-    return launch_fused<3, 2, true>(p, s);
+    return launch_fused<3, 2, 1>(p, s);
+}
+
+// First block of conv2_x: the 3x3 layer AND increase conv + projection shortcut as one contraction over two K sources.
+// out [B,H,W,C2] = relu( W2[:, :64] relu(conv3x3 + bias) + W2[:, 64:] x + bias2 ), W2 [C2][128] (make_layer_dual), x NHWC [B,H,W,64]
+// at the same pixels (stride-1 shortcut), C2 == 256.
+int wino_gemm_output_fused_incproj(const float* V, const float* U, const float* bias, const float* W2, const float* bias2, const float* x,
+                                   float* out, int B, int H, int W, int Cin, int Cout, int C2, int relu, hipStream_t s) {
+    if (!V || !U || !W2 || !bias2 || !x || !out) return MM_ERR_INVALID_ARG;
+    WinoFusedParams p;
+    p.V = V; p.U = U; p.bias = bias; p.out = out;
+    p.w2 = W2; p.bias2 = bias2; p.res = x; p.C2 = C2;
+    p.TH = (H + 3) / 4; p.TW = (W + 3) / 4;
+    const int64_t ntile = (int64_t)B * p.TH * p.TW;
+    if (!wino_fused_inc_supported(ntile, Cin, Cout, C2)) return MM_ERR_UNSUPPORTED;
+    if (ntile <= 0) return MM_OK;
+    p.ntile = (int)ntile; p.K = Cin; p.Cout = Cout; p.B = B; p.H = H; p.W = W; p.relu = relu; p.tiles_n = 0;
+    return launch_fused<3, 2, 2>(p, s);
 }
 
 }  // namespace mm

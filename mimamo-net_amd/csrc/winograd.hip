@@ -233,7 +233,7 @@ int wino_input_transform(const float* x, float* V, int B, int H, int W, int C, i
     const int TH = (H + m - 1) / m, TW = (W + m - 1) / m;
     const int64_t total = (int64_t)B * TH * TW * (C / 4);
     if (total <= 0) return MM_OK;
-    prof_before(3, (double)B * C * 4.0 * ((double)H * W + (double)((m + 2) * (m + 2)) * TH * TW), s);   // read x once, write the planes
+    prof_before(3, (double)B * C * 4.0 * ((double)H * W + (double)((m + 2) * (m + 2)) * TH * TW), s, m == 4 ? "wino_in6" : "wino_in");   // read x once, write the planes
     if (m == 4)
         hipLaunchKernelGGL(wino_in6_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, x, V, B, H, W, C / 4, x_channels / 4, TH,
                            TW, total);
@@ -249,7 +249,7 @@ int wino_output_transform(const float* M, const float* bias, float* y, int B, in
     const int TH = (H + m - 1) / m, TW = (W + m - 1) / m;
     const int64_t total = (int64_t)B * TH * TW * (Cout / 4);
     if (total <= 0) return MM_OK;
-    prof_before(3, (double)B * Cout * 4.0 * ((double)H * W + (double)((m + 2) * (m + 2)) * TH * TW), s);
+    prof_before(3, (double)B * Cout * 4.0 * ((double)H * W + (double)((m + 2) * (m + 2)) * TH * TW), s, m == 4 ? "wino_out6" : "wino_out");
     if (m == 4)
         hipLaunchKernelGGL(wino_out6_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, M, bias, y, B, H, W, Cout / 4, TH,
                            TW, relu, total);

@@ -138,7 +138,7 @@ def _count_conv_launches(fn):
     """Launches of the conv engine inside fn() (the library's measurement hook brackets each one)."""
     from mimamo_net_amd import _lib
     L = _lib.lib()
-    ms, work, n = (ctypes.c_double * 4)(), (ctypes.c_double * 4)(), (ctypes.c_int64 * 4)()
+    ms, work, n = (ctypes.c_double * 5)(), (ctypes.c_double * 5)(), (ctypes.c_int64 * 5)()
     assert L.mm_profile_begin() == 0
     fn()
     assert L.mm_profile_end(ms, work, n) == 0
@@ -414,24 +414,30 @@ def test_resnet50_full_batch_properties(resnet, dev):
     assert (sub - a[10:14]).abs().max() / a.abs().max() < 1e-5
 
 
-def test_resnet50_batch64_remainder_rows_vs_oracle(resnet, oracle, dev):
-    """At batch 64 the conv2_x increase layers (M = 200 704, 3.06 rounds) run through conv_forward's tail split: rows from
-    196 608 on -- the end of frame 62 and frame 63 -- come from the remainder launch.  Frames 60-63 (both sides of the boundary)
-    against the oracle, and against the same frames computed as a batch of 4 (no split at that size)."""
+def test_resnet50_batch64_remainder_rows_vs_oracle(resnet, oracle, dev, monkeypatch):
+    """Frames 60-63 of a batch of 64 against the oracle, and against the same frames computed as a batch of 4 -- for the default
+    schedule and for the separate-launch twin (MM_FUSE_INC=0), where the conv2_x increase layers (M = 200 704, 3.06 rounds) run
+    through conv_forward's tail split: rows from 196 608 on -- the end of frame 62 and frame 63 -- come from the remainder launch."""
+    from mimamo_net_amd.resnet50_extractor import Resnet50_Extractor
+    monkeypatch.setenv("MM_FUSE_INC", "0")
+    twin = Resnet50_Extractor(state_dict=weights.make_resnet50_state_dict(seed=0), device=dev)
+    monkeypatch.delenv("MM_FUSE_INC")
     xs = _images(64, 2)
     x = torch.from_numpy(xs).to(dev)
-    n = _count_conv_launches(lambda: resnet.get_vec(x))
-    n4 = _count_conv_launches(lambda: resnet.get_vec(x[60:64].contiguous()))
-    assert n > n4, ("expected split launches at batch 64", n, n4)
-    got = resnet.get_vec(x)[60:64].cpu().numpy()
     want = oracle.resnet50_pool5(weights.make_resnet50_state_dict(seed=0), xs[60:64])
     scale = np.abs(want).max()
-    mx, mean = np.abs(got - want).max() / scale, np.abs(got - want).mean() / scale
-    print("batch-64 frames 60-63 vs oracle: max rel %.2e mean rel %.2e (conv launches %d vs %d at batch 4)" % (mx, mean, n, n4))
-    assert mx < POOL5_RTOL * 10 and mean < POOL5_RTOL, (mx, mean)
-    assert mx < POOL5_TIGHT_MAX and mean < POOL5_TIGHT_MEAN, ("regression bound", mx, mean)
-    sub = resnet.get_vec(x[60:64].contiguous()).cpu().numpy()
-    assert np.abs(sub - got).max() / scale < 1e-5
+    for name, net in (("default", resnet), ("MM_FUSE_INC=0", twin)):
+        n = _count_conv_launches(lambda: net.get_vec(x))
+        n4 = _count_conv_launches(lambda: net.get_vec(x[60:64].contiguous()))
+        if net is twin:
+            assert n > n4, ("expected split launches at batch 64", n, n4)
+        got = net.get_vec(x)[60:64].cpu().numpy()
+        mx, mean = np.abs(got - want).max() / scale, np.abs(got - want).mean() / scale
+        print("%s: batch-64 frames 60-63 vs oracle: max rel %.2e mean rel %.2e (conv launches %d vs %d at batch 4)" % (name, mx, mean, n, n4))
+        assert mx < POOL5_RTOL * 10 and mean < POOL5_RTOL, (name, mx, mean)
+        assert mx < POOL5_TIGHT_MAX and mean < POOL5_TIGHT_MEAN, ("regression bound", name, mx, mean)
+        sub = net.get_vec(x[60:64].contiguous()).cpu().numpy()
+        assert np.abs(sub - got).max() / scale < 1e-5
 
 
 def test_zero_sized_calls_are_noops(pkg, dev):
@@ -636,7 +642,7 @@ def test_resnet50_increase_conv_inside_the_fused_winograd_kernel(resnet, oracle,
     scale = np.abs(want).max()
     n_f = _count_conv_launches(lambda: resnet.get_vec(xt))
     n_s = _count_conv_launches(lambda: split.get_vec(xt))
-    assert n_s - n_f == 2, ("two increase launches fewer with the fused form", n_f, n_s)
+    assert n_s - n_f == 3, ("two increase launches and one increase+projection launch fewer with the fused form", n_f, n_s)
     try:
         for mode in (1, 5):
             resnet.set_winograd(mode)

@@ -17,7 +17,7 @@ for bs in [int(a) for a in sys.argv[1:]] or [16, 32, 64, 128, 1024]:
         rn.get_vec(x, channels_last4=True)
     torch.cuda.synchronize()
     os.environ["MM_PROF_DUMP"] = "/tmp/sweep_%d.csv" % bs
-    ms = (ctypes.c_double * 4)(); work = (ctypes.c_double * 4)(); n = (ctypes.c_int64 * 4)()
+    ms = (ctypes.c_double * 5)(); work = (ctypes.c_double * 5)(); n = (ctypes.c_int64 * 5)()
     L.mm_profile_begin()
     rn.get_vec(x, channels_last4=True)
     L.mm_profile_end(ms, work, n)

@@ -7,8 +7,7 @@ import os
 import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-dump = "/tmp/mm_prof_dump.csv"
-os.environ["MM_PROF_DUMP"] = dump
+dump = os.environ.setdefault("MM_PROF_DUMP", "/tmp/mm_prof_dump.csv")
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 import mimamo_net_amd  # noqa: E402,F401
@@ -30,14 +29,14 @@ with torch.no_grad():
     torch.cuda.synchronize()
     L.mm_profile_begin()
     hot.forward_u8(frames, plan, True)
-    ms, wk, ln = (ctypes.c_double * 4)(), (ctypes.c_double * 4)(), (ctypes.c_int64 * 4)()
+    ms, wk, ln = (ctypes.c_double * 5)(), (ctypes.c_double * 5)(), (ctypes.c_int64 * 5)()
     assert L.mm_profile_end(ms, wk, ln) == 0
 agg = collections.OrderedDict()
 for line in open(dump):
     cat, work, t, tag = line.rstrip("\n").split(",", 3)
     a = agg.setdefault((int(cat), tag), [0, 0.0, 0.0])
     a[0] += 1; a[1] += float(work); a[2] += float(t)
-names = {0: "conv", 1: "pyramid", 2: "window", 3: "wino-xf"}
+names = {0: "conv", 1: "pyramid", 2: "window", 3: "wino-xf", 4: "other"}
 tot = collections.Counter()
 for (cat, tag), (n, work, t) in agg.items():
     rate = work / (t * 1e-3) / 1e12 if cat == 0 else work / (t * 1e-3) / 1e9

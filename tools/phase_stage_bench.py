@@ -26,7 +26,7 @@ for clips in [int(a) for a in sys.argv[1:]] or [1, 11, 32, 256]:
             f()
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / 20
-        ms = (ctypes.c_double * 4)(); work = (ctypes.c_double * 4)(); launches = (ctypes.c_int64 * 4)()
+        ms = (ctypes.c_double * 5)(); work = (ctypes.c_double * 5)(); launches = (ctypes.c_int64 * 5)()
         L.mm_profile_begin()
         for _ in range(5):
             f()
