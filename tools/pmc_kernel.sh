@@ -1,12 +1,13 @@
 #!/bin/bash
 # PMC counters of one kernel (name substring $1) over a single-stream step: matrix-pipe busy fraction, effective clock, wave
-# stall breakdown.  usage: gpurun -- 'bash tools/pmc_kernel.sh wino_fused_kernel [clips] [winograd mode]'
+# stall breakdown.  usage: gpurun -- 'bash tools/pmc_kernel.sh wino_fused_kernel [clips] [winograd mode]'   (PK_DRIVER=<script>: another
+# driver program than tools/layer_table.py, e.g. tools/probes/stem_probe.py)
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 PAT=${1:-conv_mfma_kernel}; CL=${2:-32}; MODE=${3:-1}
 rm -rf /tmp/pk
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE SQ_BUSY_CU_CYCLES \
-   --kernel-trace --output-format csv -d /tmp/pk -o out -- python $R/tools/layer_table.py $CL $MODE > /tmp/pk.log 2>&1
+   --kernel-trace --output-format csv -d /tmp/pk -o out -- python ${PK_DRIVER:-$R/tools/layer_table.py} $CL $MODE > /tmp/pk.log 2>&1
 f=$(find /tmp/pk -name "*counter_collection.csv" | head -1)
 t=$(find /tmp/pk -name "*kernel_trace.csv" | head -1)
 python - "$f" "$t" "$PAT" <<'PY'
