@@ -316,3 +316,28 @@ def test_image_sampler_dataset(tmp_path):
     assert tuple(default.shape) == (3, 112, 112) and abs(float(default.mean())) < 3.0
     with pytest.raises(NotImplementedError):
         Image_Sampler("v", root)                 # the reference's default is test_mode=False: training-time sampling
+
+
+def test_profiles_hold_pmc_summaries_for_the_head_kernel_sources():
+    """bench.py quotes roofline.traffic / roofline_phase.traffic / roofline.mixed_frac from PMC summaries under profiles/ and only
+    while their `kernel_source_hash` equals the hash of mimamo-net_amd/csrc at HEAD: a kernel edit without a profile refresh would
+    silently null those fields in the driver's line (round-3 verdict, weak item 9).  This test is the reminder."""
+    import glob
+    import json
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import bench
+    head = bench.kernel_source_hash()
+    found = {}
+    for kind in ("conv_traffic", "phase_traffic", "layer_bytes"):
+        for path in glob.glob(os.path.join(root, "profiles", "*%s*.json" % kind)):
+            d = json.load(open(path))
+            if d.get("kernel_source_hash") == head and d.get("clips_per_gpu") == 32:
+                found[kind] = (os.path.basename(path), d)
+    assert set(found) == {"conv_traffic", "phase_traffic", "layer_bytes"}, (
+        "profiles/ has no PMC summary for kernel-source hash %s: re-run tools/profile_round.sh on the GPU box and copy "
+        "gpurun_out/r0N_{conv,phase}_traffic_32clips.json + r0N_layer_bytes_32clips.json to profiles/ (found: %s)" % (head, sorted(found)))
+    assert found["conv_traffic"][1]["bytes_per_step"] > 1e11 and found["phase_traffic"][1]["bytes_per_step"] > 5e8
+    lb = found["layer_bytes"][1]
+    assert len(lb["launches"]) > 90 and 0.5 < lb["mixed_frac"] < 1.0 and lb["step_floor_ms"] > 60
