@@ -26,10 +26,23 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+def _file_flags(src):
+    """Per-file compiler flags: a source may carry a line `// mm-hipcc-flags: <flags>` near its top (e.g. a backend option one of its
+    kernels needs)."""
+    out = []
+    with open(src) as f:
+        for i, line in enumerate(f):
+            if i > 80:
+                break
+            if "mm-hipcc-flags:" in line:
+                out += line.split("mm-hipcc-flags:", 1)[1].split()
+    return out
+
+
 def _compile(src, headers):
     obj = os.path.splitext(src)[0] + ".o"
     if _stale(obj, [src] + headers):
-        cmd = [HIPCC] + FLAGS + (["-x", "hip"] if src.endswith(".cpp") else []) + ["-c", src, "-o", obj]
+        cmd = [HIPCC] + FLAGS + _file_flags(src) + (["-x", "hip"] if src.endswith(".cpp") else []) + ["-c", src, "-o", obj]
         r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, universal_newlines=True)
         if r.returncode != 0:
             raise RuntimeError("hipcc failed on %s:\n%s" % (src, r.stdout))

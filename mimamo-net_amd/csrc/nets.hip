@@ -405,7 +405,8 @@ int mm_resnet50_create(mm_resnet50_t** out, const float* blob, int64_t n_floats,
         const char* fp = getenv("MM_FUSE_PROJ");   // measurement knob: 0 = projection shortcut as its own launch + residual read
         h->fuse_proj = fp ? atoi(fp) : 1;
         const char* fi = getenv("MM_FUSE_INC");    // measurement knob: 0 = 3x3 and increase conv as separate launches (the parity twin)
-        h->fuse_inc = fi ? atoi(fi) : 2;           // 1 = blocks 2, 3 only; 2 (default) = also block 1 (increase | projection over two K sources)
+        // 1 = conv2_x blocks 2, 3 only; 2 = also block 1 (increase | projection over two K sources); 3 = also conv3_x blocks 2-4
+        h->fuse_inc = fi ? atoi(fi) : 3;
     }
     auto conv_bn = [&](Layer& L, int cout, int cin, int k, int stride, int pad, int relu) {
         const float* w = p;
@@ -552,8 +553,9 @@ int mm_resnet50_forward(mm_resnet50_t* h, const float* images, int nchw, int64_t
         if (wm_ && Bk.conv3.wino_u &&
             (int64_t)(wt_ + 2) * (wt_ + 2) * ((H1 + wt_ - 1) / wt_) * ((W1 + wt_ - 1) / wt_) * Bk.conv3.cin <= kRsWino) {
             rc = MM_ERR_UNSUPPORTED;
-            if (wm_ == 5 && h->fuse_inc && !Bk.has_proj) {
-                // conv2_x blocks 2, 3 (Cin = Cout = 64 -> 256): 3x3 + increase + residual + ReLU in one kernel
+            if (wm_ == 5 && h->fuse_inc && !Bk.has_proj && (Bk.conv3.cout == 64 || h->fuse_inc >= 3)) {
+                // conv2_x blocks 2, 3 (Cin = Cout = 64 -> 256) and, with MM_FUSE_INC >= 3, conv3_x blocks 2-4 (128 -> 512): 3x3 +
+                // increase + residual + ReLU in one kernel
                 rc = run_layer_wino(Bk.conv3, y1, B, H1, W1, nullptr, wv, nullptr, 5, s, &Bk.increase, x, o);
                 inc_done = rc == MM_OK;
             } else if (wm_ == 5 && h->fuse_inc >= 2 && dual && Bk.proj_stride == 1 && C == Bk.conv3.cout && H1 == H && W1 == W) {

@@ -20,6 +20,12 @@
 // column-first); results agree with the three-kernel form to fp32 rounding.
 // The reference computes these layers with torch's direct fp32 conv (third-party ResNet50, api/resnet50_extractor.py:74-83);
 // parity is checked against the oracle's direct convolution.
+//
+// mm-hipcc-flags: -mllvm -amdgpu-promote-alloca-to-vector-limit=4096
+// (build.py passes this to hipcc for this file.  The eight-wave INC 3 instantiation has more per-thread arrays than the backend's
+//  default promote-to-vector budget for a 512-thread workgroup: without it half of the 128-register Y array stays in scratch --
+//  272 bytes per lane, element-wise scratch stores in the transform -- although only 190 VGPRs are in use.  The other
+//  instantiations compile to the same registers / scratch with and without the option.)
 #include <cstdio>
 #include <cstdlib>
 #include <type_traits>
@@ -51,12 +57,15 @@ static constexpr float kAtHost[4][6] = {{1, 1, 1, 1, 1, 0}, {0, 1, -1, 2, -2, 0}
 // from the accumulator registers -- in that layout they ARE the B operand of the second MFMA -- adds the residual, applies the ReLU
 // and writes the block's 256-channel output: the 64-channel tensor between the 3x3 and the increase conv (1.6 MB per frame written
 // and re-read) never exists, and the 49 %-busy K = 64 GEMM launch disappears.
-template <int NBUF, int WGM, int INC = 0>
-__global__ void __launch_bounds__(WGM * 128) __attribute__((amdgpu_waves_per_eu(2, 2)))
+// WGN = 4 (INC 3, conv3_x blocks 2-4: Cin = Cout = 128, increase 128 -> 512): eight waves as 2 x 4, 32 tiles x 128 channels -- the
+// workgroup again owns every channel of its pixels -- one workgroup per CU (120 KB ring); the 256 KB increase matrix passes through
+// LDS in four row quarters.
+template <int NBUF, int WGM, int INC = 0, int WGN = 2>
+__global__ void __launch_bounds__(WGM * WGN * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
 wino_fused_kernel(const WinoFusedParams p) {
     // WGM = 4: eight waves, 64 tiles x 64 channels, one workgroup per CU; WGM = 2: four waves, 32 tiles x 64 channels, two
     // independent workgroups per CU (no common barrier between the two waves of a SIMD)
-    constexpr int NW = 2 * WGM, BM = 16 * WGM, BN = 64, KS = 64;
+    constexpr int NW = WGN * WGM, BM = 16 * WGM, BN = 32 * WGN, KS = 64;
     constexpr int ROWS = BM + BN;
     constexpr int NIA = BM / (4 * NW), NIB = BN / (4 * NW);   // 2 + 2 pieces of 1 KB (4 rows) per wave per slab
     constexpr int NL = NIA + NIB;
@@ -64,7 +73,7 @@ wino_fused_kernel(const WinoFusedParams p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;               // 16 tiles x 32 channels per wave
+    const int wm = wave / WGN, wn = wave % WGN;            // 16 tiles x 32 channels per wave
     const int l16 = lane & 15, lg = lane >> 4;             // MFMA operand row / column, k index inside a k-step of 4
     // the n-tiles of an m-tile are neighbours in the logical order and stay on one XCD: its L2 serves the V rows they share
     const int logical = xcd_contiguous(blockIdx.x, gridDim.x);
@@ -126,8 +135,21 @@ wino_fused_kernel(const WinoFusedParams p) {
                            "s"(ra), "s"(rb), "s"(base), "n"(0), "n"(NW * 1024), "n"(BM * KS * 4), "n"(BM * KS * 4 + NW * 1024),
                            "n"(BM * KS * 4 + 2 * NW * 1024), "n"(BM * KS * 4 + 3 * NW * 1024)
                          : "memory", "scc");
+        } else if constexpr (NIA == 1 && NIB == 4) {
+            asm volatile("s_mov_b32 %0, m0\n\t"
+                         "s_add_u32 m0, %8, %9\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %6, 0 offen lds\n\t"
+                         "s_add_u32 m0, %8, %10\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %7, 0 offen lds\n\t"
+                         "s_add_u32 m0, %8, %11\n\ts_nop 0\n\tbuffer_load_dwordx4 %3, %7, 0 offen lds\n\t"
+                         "s_add_u32 m0, %8, %12\n\ts_nop 0\n\tbuffer_load_dwordx4 %4, %7, 0 offen lds\n\t"
+                         "s_add_u32 m0, %8, %13\n\ts_nop 0\n\tbuffer_load_dwordx4 %5, %7, 0 offen lds\n\t"
+                         "s_mov_b32 m0, %0"
+                         : "=&s"(keep)
+                         : "v"(va[0] + koff), "v"(vb[0] + koff), "v"(vb[1] + koff), "v"(vb[2] + koff), "v"(vb[3] + koff),
+                           "s"(ra), "s"(rb), "s"(base), "n"(0), "n"(BM * KS * 4), "n"(BM * KS * 4 + NW * 1024),
+                           "n"(BM * KS * 4 + 2 * NW * 1024), "n"(BM * KS * 4 + 3 * NW * 1024)
+                         : "memory", "scc");
         } else {
-            static_assert(NIA == 2 && NIB == 2, "piece counts of the two workgroup shapes");
+            static_assert(NIA == 2 && NIB == 2, "piece counts of the workgroup shapes");
             asm volatile("s_mov_b32 %0, m0\n\t"
                          "s_add_u32 m0, %7, %8\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %5, 0 offen lds\n\t"
                          "s_add_u32 m0, %7, %9\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %5, 0 offen lds\n\t"
@@ -278,6 +300,132 @@ wino_fused_kernel(const WinoFusedParams p) {
     update_y(5);
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");   // tail loads drained, everyone done with the ring
 
+    if constexpr (INC == 3) {
+        // ---- conv3_x blocks 2-4: out = relu( W2 relu(Y + bias) + bias2 + res ), W2 [512][128].  A wave holds 32 of the 128 channels of
+        // its 16 tiles; the three waves with the other channels of the same tiles (same wm) hand over lane-for-lane register copies
+        // through a double-buffered exchange area (one barrier per position).  The matrix goes through LDS in four passes of 128
+        // rows (64 KB); wave (wm, wn) produces channels [128 pass + 32 wn, + 32) of its 16 tiles: 64 MFMAs per position and pass.
+        static_assert(WGM == 2 && WGN == 4 && NBUF == 3, "INC 3 is built for the 2 x 4 wave workgroup");
+        constexpr int K2 = 128, ROWS2 = 128;
+        constexpr int W2_FLOATS = ROWS2 * K2;                          // 64 KB
+        constexpr int XB_FLOATS = NW * 512;                            // one exchange buffer: 8 waves x 2 KB
+        static_assert((W2_FLOATS + 2 * XB_FLOATS + 512) * 4 <= NBUF * ROWS * KS * 4, "epilogue tenants fit the dead ring");
+        float* xb = lds + W2_FLOATS;
+        float* b2s = xb + 2 * XB_FLOATS;
+        // (The exchange only couples the four waves of one tile half (same wm).  A per-half barrier on an LDS counter -- ds_add to
+        //  arrive, poll to wait -- instead of the workgroup-wide s_barrier below was built and measured: 103.64-103.84 vs
+        //  103.30-103.66 ms per step on one box, profiles/r04_ab_inc3_barrier.txt: the polling costs what the decoupling gains.)
+        f32x4v b1[2];
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb) {
+            const float4 t = p.bias ? *reinterpret_cast<const float4*>(p.bias + wn * 32 + cb * 16 + 4 * lg) : float4{0.f, 0.f, 0.f, 0.f};
+            b1[cb] = f32x4v{t.x, t.y, t.z, t.w};
+        }
+        const int tpi = p.TH * p.TW;
+        const int t = m_base + wm * 16 + l16;
+        const bool tok = t < p.ntile;
+        const int tt = tok ? t : 0;
+        const int bimg = tt / tpi, rem = tt - bimg * tpi;
+        const int ty = rem / p.TW, tx = rem - ty * p.TW;
+        const int64_t pix0 = ((int64_t)bimg * p.H + 4 * ty) * p.W + 4 * tx;
+        // A-operand offsets inside a pass's 128 x 128 block: row 32 wn + 16 j + l16, k-quad (8 src + 4 cb + lg) ^ l16; sidx 0-1 = own
+        // channel blocks, 2-7 = the three partners' (source wave column (wn + 1 + (sidx - 2) / 2) % 4)
+        int wa[8], xr[3];
+#pragma unroll
+        for (int sidx = 0; sidx < 8; ++sidx) {
+            const int src = sidx < 2 ? wn : (wn + 1 + (sidx - 2) / 2) & 3;
+            const int qd = (src * 8 + (sidx & 1) * 4 + lg) ^ l16;
+            wa[sidx] = (wn * 32 + l16) * K2 + (qd << 2);
+        }
+#pragma unroll
+        for (int k = 0; k < 3; ++k) xr[k] = ((wm * 4 + ((wn + 1 + k) & 3)) * 8 + lg) * 64 + l16 * 4;
+        const int x_own = (wave * 8 + lg) * 64 + l16 * 4;
+        for (int i = tid; i < 512; i += NW * 64) b2s[i] = p.bias2[i];
+#pragma unroll
+        for (int pp = 0; pp < 4; ++pp)
+#pragma unroll
+            for (int qq = 0; qq < 4; ++qq)
+#pragma unroll
+                for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float v = Y[pp][qq][cb][e] + b1[cb][e];
+                        Y[pp][qq][cb][e] = p.relu ? fmaxf(v, 0.f) : v;
+                    }
+        for (int pass = 0; pass < 4; ++pass) {
+            // (later passes: every wave is past its last read of the previous quarter; its stores are drained so that the counted
+            //  wait below sees only this pass's loads)
+            if (pass) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            {
+                const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.w2) + (int64_t)pass * W2_FLOATS, 0,
+                                                                                    (unsigned)(W2_FLOATS * 4), 0x00020000);
+#pragma unroll
+                for (int it = 0; it < ROWS2 / (2 * NW); ++it) {
+                    const int row = (it * NW + wave) * 2 + (lane >> 5);
+                    const unsigned voff = (unsigned)(row * K2 + (((lane & 31) ^ (row & 15)) << 2)) * 4u;
+                    dma1(rw, voff, lds0 + (unsigned)((it * NW + wave) * 1024));
+                }
+            }
+            const int c0 = pass * 128 + wn * 32 + 4 * lg;               // first output channel of this lane in this pass
+            const float* rbase = p.res + pix0 * p.C2 + c0;
+            float* obase = p.out + pix0 * p.C2 + c0;
+            auto res_rows = [&](f32x4v (&r)[2], int pos) {
+                const int pp = pos >> 2, qq = pos & 3;
+                const bool pok = tok && 4 * ty + pp < p.H && 4 * tx + qq < p.W;
+                const float* rp = pok ? rbase + ((int64_t)pp * p.W + qq) * p.C2 : p.res + c0;
+#pragma unroll
+                for (int j = 0; j < 2; ++j) r[j] = *reinterpret_cast<const f32x4v*>(rp + j * 16);
+            };
+            f32x4v rs[2][2], Pr[3][2];
+            res_rows(rs[0], 0);
+            asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)\n\ts_barrier" ::: "memory");   // the matrix quarter landed (2 residual loads may still fly)
+#pragma unroll
+            for (int pos = 0; pos < 16; ++pos) {
+                const int pp = pos >> 2, qq = pos & 3;
+                float* xbuf = xb + (pos & 1) * XB_FLOATS;
+#pragma unroll
+                for (int cb = 0; cb < 2; ++cb) *reinterpret_cast<f32x4v*>(xbuf + x_own + cb * 256) = Y[pp][qq][cb];
+                // one barrier per position: buffer (pos & 1) was last read at position pos - 2, and every wave has passed the
+                // barrier of position pos - 1 -- i.e. finished those reads (lgkmcnt(0) before it) -- before anyone writes it again
+                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#pragma unroll
+                for (int k = 0; k < 3; ++k)
+#pragma unroll
+                    for (int cb = 0; cb < 2; ++cb) Pr[k][cb] = *reinterpret_cast<const f32x4v*>(xbuf + xr[k] + cb * 256);
+                if (pos + 1 < 16) res_rows(rs[(pos + 1) & 1], pos + 1);
+                f32x4v acc[2];
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[j] = *reinterpret_cast<const f32x4v*>(b2s + c0 + j * 16);
+#pragma unroll
+                for (int sidx = 0; sidx < 8; ++sidx) {
+                    const f32x4v Bv = sidx < 2 ? Y[pp][qq][sidx & 1] : Pr[(sidx - 2) >> 1][sidx & 1];
+                    float4 w4[2];
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) w4[j] = *reinterpret_cast<const float4*>(lds + wa[sidx] + (j * 16) * K2);
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(w4[j].x, Bv[0], acc[j], 0, 0, 0);
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(w4[j].y, Bv[1], acc[j], 0, 0, 0);
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(w4[j].z, Bv[2], acc[j], 0, 0, 0);
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(w4[j].w, Bv[3], acc[j], 0, 0, 0);
+                }
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    acc[j] = acc[j] + rs[pos & 1][j];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[j][e] = fmaxf(acc[j][e], 0.f);
+                }
+                if (tok && 4 * ty + pp < p.H && 4 * tx + qq < p.W) {
+                    float* op = obase + ((int64_t)pp * p.W + qq) * p.C2;
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) __builtin_nontemporal_store(acc[j], reinterpret_cast<f32x4v*>(op + j * 16));
+                }
+            }
+        }
+        return;
+    }
     if constexpr (INC == 2) {
         // ---- first block of conv2_x: increase conv + projection shortcut as ONE contraction over K = 64 (this layer's output) + 64 (the
         // block input x at the same pixels): out = relu( [W2a | W2b] [relu(Y + bias); x] + bias2 ), W2 = [256][128] (make_layer_dual).
@@ -553,34 +701,35 @@ wino_fused_kernel(const WinoFusedParams p) {
     }
 }
 
-template <int NBUF, int WGM, int INC = 0>
+template <int NBUF, int WGM, int INC = 0, int WGN = 2>
 static int launch_fused(WinoFusedParams p, hipStream_t s) {
-    constexpr int BM = 16 * WGM;
+    constexpr int BM = 16 * WGM, BN = 32 * WGN;
     // INC: the increase matrix (64 KB) + exchange area (8 KB) take the dead operand ring, bias2 (1 KB) sits behind it: 73 KB, two
     // workgroups per CU still fit the 160 KB
-    constexpr int LDS_BYTES = INC ? (256 * 64 + 2048 + 256) * 4 : NBUF * (BM + 64) * 64 * 4;
-    static_assert(!INC || LDS_BYTES >= NBUF * (BM + 64) * 64 * 4, "the ring must fit too");
+    constexpr int LDS_BYTES = (INC == 1 || INC == 2) ? (256 * 64 + 2048 + 256) * 4 : NBUF * (BM + BN) * 64 * 4;
+    static_assert(LDS_BYTES >= NBUF * (BM + BN) * 64 * 4, "the ring must fit too");
     static bool attr_set[16] = {};
     int dev = 0;
     (void)hipGetDevice(&dev);
     if (dev >= 0 && dev < 16 && !attr_set[dev]) {
-        MM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(wino_fused_kernel<NBUF, WGM, INC>), hipFuncAttributeMaxDynamicSharedMemorySize,
+        MM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(wino_fused_kernel<NBUF, WGM, INC, WGN>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                    LDS_BYTES));
         attr_set[dev] = true;
     }
-    p.tiles_n = (p.Cout + 63) / 64;
+    p.tiles_n = (p.Cout + BN - 1) / BN;
     for (int q = 0; q < 6; ++q)
         for (int qq = 0; qq < 4; ++qq) p.at_cols[q * 4 + qq] = kAtHost[qq][q];
     const int64_t blocks = (int64_t)((p.ntile + BM - 1) / BM) * p.tiles_n;
     if (blocks <= 0 || blocks > 0x7fffffff) return MM_ERR_INVALID_ARG;
     if (prof_enabled()) {
         char tag[64];
-        snprintf(tag, sizeof(tag), "wino-fused%s M=%d K=%d N=%d t%dx64 b36", INC == 2 ? "+incproj256" : INC ? "+inc256" : "", p.ntile, p.K, p.Cout, BM);
+        snprintf(tag, sizeof(tag), "wino-fused%s M=%d K=%d N=%d t%dx%d b36", INC == 3 ? "+inc512" : INC == 2 ? "+incproj256" : INC ? "+inc256" : "", p.ntile,
+                 p.K, p.Cout, BM, BN);
         double fl = 2.0 * 36.0 * (double)p.ntile * (double)p.K * (double)p.Cout;
         if (INC) fl += 2.0 * (double)p.B * p.H * p.W * (double)(INC == 2 ? 2 * p.Cout : p.Cout) * (double)p.C2;
         prof_before(0, fl, s, tag);
     }
-    hipLaunchKernelGGL((wino_fused_kernel<NBUF, WGM, INC>), dim3((unsigned)blocks), dim3(WGM * 128), LDS_BYTES, s, p);
+    hipLaunchKernelGGL((wino_fused_kernel<NBUF, WGM, INC, WGN>), dim3((unsigned)blocks), dim3(WGM * WGN * 64), LDS_BYTES, s, p);
     prof_after(0, s);
     MM_LAUNCH_CHECK();
     return MM_OK;
@@ -593,7 +742,7 @@ bool wino_fused_supported(int64_t ntile, int Cin, int Cout) {
 }
 
 bool wino_fused_inc_supported(int64_t ntile, int Cin, int Cout, int C2) {
-    return Cout == 64 && C2 == 256 && wino_fused_supported(ntile, Cin, Cout);
+    return ((Cout == 64 && C2 == 256) || (Cout == 128 && C2 == 512)) && wino_fused_supported(ntile, Cin, Cout);
 }
 
 // V [36][ntile][Cin] (from wino_input_transform, m = 4), U [36][Cout][Cin] -> y NHWC [B,H,W,Cout] (+bias, ReLU)
@@ -626,6 +775,7 @@ int wino_gemm_output_fused_inc(const float* V, const float* U, const float* bias
     if (!wino_fused_inc_supported(ntile, Cin, Cout, C2)) return MM_ERR_UNSUPPORTED;
     if (ntile <= 0) return MM_OK;
     p.ntile = (int)ntile; p.K = Cin; p.Cout = Cout; p.B = B; p.H = H; p.W = W; p.relu = relu; p.tiles_n = 0;
+    if (Cout == 128) return launch_fused<3, 2, 3, 4>(p, s);     // conv3_x: 2 x 4 waves, 32 tiles x 128 channels, 128 -> 512
     return launch_fused<3, 2, 1>(p, s);
 }
 
@@ -640,7 +790,7 @@ int wino_gemm_output_fused_incproj(const float* V, const float* U, const float* 
     p.w2 = W2; p.bias2 = bias2; p.res = x; p.C2 = C2;
     p.TH = (H + 3) / 4; p.TW = (W + 3) / 4;
     const int64_t ntile = (int64_t)B * p.TH * p.TW;
-    if (!wino_fused_inc_supported(ntile, Cin, Cout, C2)) return MM_ERR_UNSUPPORTED;
+    if (Cout != 64 || !wino_fused_inc_supported(ntile, Cin, Cout, C2)) return MM_ERR_UNSUPPORTED;
     if (ntile <= 0) return MM_OK;
     p.ntile = (int)ntile; p.K = Cin; p.Cout = Cout; p.B = B; p.H = H; p.W = W; p.relu = relu; p.tiles_n = 0;
     return launch_fused<3, 2, 2>(p, s);

@@ -642,7 +642,7 @@ def test_resnet50_increase_conv_inside_the_fused_winograd_kernel(resnet, oracle,
     scale = np.abs(want).max()
     n_f = _count_conv_launches(lambda: resnet.get_vec(xt))
     n_s = _count_conv_launches(lambda: split.get_vec(xt))
-    assert n_s - n_f == 3, ("two increase launches and one increase+projection launch fewer with the fused form", n_f, n_s)
+    assert n_s - n_f == 6, ("conv2_x: two increase + one increase|projection launch, conv3_x: three increase launches fewer", n_f, n_s)
     try:
         for mode in (1, 5):
             resnet.set_winograd(mode)
