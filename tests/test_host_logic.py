@@ -341,3 +341,11 @@ def test_profiles_hold_pmc_summaries_for_the_head_kernel_sources():
     assert found["conv_traffic"][1]["bytes_per_step"] > 1e11 and found["phase_traffic"][1]["bytes_per_step"] > 5e8
     lb = found["layer_bytes"][1]
     assert len(lb["launches"]) > 90 and 0.5 < lb["mixed_frac"] < 1.0 and lb["step_floor_ms"] > 60
+
+
+def test_parse_partitions():
+    from mimamo_net_amd.stream import parse_partitions
+    assert parse_partitions("") is None
+    lanes = parse_partitions("0-127/128-255")
+    assert [len(l) for l in lanes] == [128, 128] and lanes[0][0] == 0 and lanes[1][-1] == 255
+    assert parse_partitions("0-3,8,10-11/5") == [[0, 1, 2, 3, 8, 10, 11], [5]]
