@@ -43,6 +43,10 @@ int nchw_to_nhwc(const float* in, float* out, int64_t N, int C, int HW, int cstr
 int nchw3_to_bordered_nhwc3(const float* in, float* out, int64_t N, int S, int pad, hipStream_t s);
 // MaxPool2d(k=3, s=2, pad=0, ceil_mode) on NHWC
 int maxpool3x3s2(const float* in, float* out, int64_t N, int H, int W, int C, int Ho, int Wo, hipStream_t s);
+// the same pool AND the 1x1 conv that follows it at conv2_1 (64 -> 64, w [64][64] BN-folded, + bias, ReLU) in one kernel (pool_reduce.hip):
+// x_out = the pooled tensor (bit-identical to maxpool3x3s2), y_out = relu?(w x + bias); NHWC, 64 channels
+int maxpool_reduce64(const float* in, const float* w, const float* bias, float* x_out, float* y_out, int64_t N, int H, int W, int Ho, int Wo,
+                     int relu, hipStream_t s);
 // global average pool over HW (AvgPool2d(k=HW side)); optional ReLU afterwards
 int avgpool_hw(const float* in, float* out, int64_t N, int HW, int C, int out_cstride, int out_coff, int relu, hipStream_t s);
 // Winograd F(m x m, 3x3) transforms around a batched GEMM (winograd.hip), m = 2 or 4, a = m + 2

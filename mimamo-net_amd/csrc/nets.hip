@@ -291,6 +291,7 @@ struct mm_resnet50 {
     int ceil_mode;
     int winograd;  // 0 direct, 2 = F(2x2,3x3), 4 = F(4x4,3x3) for the layers that have Winograd-domain weights
     int fuse_proj; // 1 (default): the first block of a stage runs increase + projection as one launch
+    int fuse_pool; // 1 (default): pool1 and conv2_1's 1x1 reduce conv run as one kernel (pool_reduce.hip)
     int fuse_inc;  // 1 (default): conv2_x blocks without a projection run 3x3 + increase + residual in ONE kernel (wino_fused.hip INC)
     int device;
 };
@@ -404,6 +405,8 @@ int mm_resnet50_create(mm_resnet50_t** out, const float* blob, int64_t n_floats,
     {
         const char* fp = getenv("MM_FUSE_PROJ");   // measurement knob: 0 = projection shortcut as its own launch + residual read
         h->fuse_proj = fp ? atoi(fp) : 1;
+        const char* fpl = getenv("MM_FUSE_POOL");  // measurement knob: 0 = max-pool and conv2_1's reduce conv as two launches (the parity twin)
+        h->fuse_pool = fpl ? atoi(fpl) : 1;
         const char* fi = getenv("MM_FUSE_INC");    // measurement knob: 0 = 3x3 and increase conv as separate launches (the parity twin)
         // 1 = conv2_x blocks 2, 3 only; 2 = also block 1 (increase | projection over two K sources); 3 = also conv3_x blocks 2-4
         h->fuse_inc = fi ? atoi(fi) : 3;
@@ -526,7 +529,17 @@ int mm_resnet50_forward(mm_resnet50_t* h, const float* images, int nchw, int64_t
     } else {
         Ho = (H - 3) / 2 + 1; Wo = (W - 3) / 2 + 1;
     }
-    rc = maxpool3x3s2(big[0], big[1], batch, H, W, 64, Ho, Wo, s);
+    // pool1 + conv2_1_1x1_reduce in one kernel when that block starts with a stride-1 64 -> 64 1x1 conv (the published graph)
+    bool pooled_reduce = false;
+    {
+        const Layer& R = h->blocks.front().reduce;
+        if (h->fuse_pool && R.k == 1 && R.stride == 1 && R.pad == 0 && R.cin_p == 64 && R.cout == 64 && R.Kpad == 64 && R.korder == 0 && !R.ps) {
+            rc = maxpool_reduce64(big[0], R.w, R.bias, big[1], y1, batch, H, W, Ho, Wo, R.relu, s);
+            pooled_reduce = true;
+        } else {
+            rc = maxpool3x3s2(big[0], big[1], batch, H, W, 64, Ho, Wo, s);
+        }
+    }
     if (rc != MM_OK) return rc;
     H = Ho; W = Wo;
     int xi = 1;  // index of the buffer holding the block input
@@ -543,8 +556,12 @@ int mm_resnet50_forward(mm_resnet50_t* h, const float* images, int nchw, int64_t
             if (rc != MM_OK) return rc;
             resid = sc;
         }
-        rc = run_layer(Bk.reduce, x, B, H, W, C, 0, y1, Bk.reduce.cout, 0, nullptr, 0, s, &H1, &W1);
-        if (rc != MM_OK) return rc;
+        if (pooled_reduce && &Bk == &h->blocks.front()) {
+            H1 = H; W1 = W;                        // y1 was written by the pool kernel
+        } else {
+            rc = run_layer(Bk.reduce, x, B, H, W, C, 0, y1, Bk.reduce.cout, 0, nullptr, 0, s, &H1, &W1);
+            if (rc != MM_OK) return rc;
+        }
         // default (1): conv2_x..conv4_x (Cin <= 256) take the fused kernel, conv5_x the three-kernel form (Cin = 512: its
         // position GEMMs are matrix-core bound, 135 vs 109 TFLOP/s, and its M planes are small); per layer in DESIGN.md
         const int wm_ = h->winograd == 1 ? (Bk.conv3.cin <= g_wino_fused_max_cin ? 5 : 4) : h->winograd;

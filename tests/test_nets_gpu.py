@@ -668,6 +668,41 @@ def test_resnet50_increase_conv_inside_the_fused_winograd_kernel(resnet, oracle,
     assert (resnet.get_vec(xt[1:2].contiguous()) - a[1:2]).abs().max().item() / scale < 1e-5
 
 
+def test_resnet50_maxpool_and_reduce_conv_in_one_kernel(resnet, oracle, dev, monkeypatch):
+    """pool1_3x3_s2 + conv2_1's 1x1 reduce conv (64 -> 64) as one kernel (pool_reduce.hip: the pooled values go from the max straight
+    into the MFMA as its B operand) against the two-launch form (MM_FUSE_POOL=0) and the oracle; odd batch: 3 x 3136 pixels = 588
+    groups of 16."""
+    from mimamo_net_amd.resnet50_extractor import Resnet50_Extractor
+    monkeypatch.setenv("MM_FUSE_POOL", "0")
+    split = Resnet50_Extractor(state_dict=weights.make_resnet50_state_dict(seed=0), device=dev)
+    monkeypatch.delenv("MM_FUSE_POOL")
+    x = _images(3, 19)
+    want = oracle.resnet50_pool5(weights.make_resnet50_state_dict(seed=0), x)
+    xt = torch.from_numpy(x).to(dev)
+    scale = np.abs(want).max()
+    n_f = _count_conv_launches(lambda: resnet.get_vec(xt))
+    n_s = _count_conv_launches(lambda: split.get_vec(xt))
+    assert n_s - n_f == 1, ("the reduce conv is no conv-engine launch any more", n_f, n_s)
+    try:
+        for mode in (1, 0):
+            resnet.set_winograd(mode)
+            split.set_winograd(mode)
+            a, b = resnet.get_vec(xt).cpu().numpy(), split.get_vec(xt).cpu().numpy()
+            assert not np.array_equal(a, b)
+            d = np.abs(a - b).max() / scale
+            print("winograd %d: pool+reduce fused vs two launches max rel %.2e; vs oracle %.2e / %.2e" % (
+                mode, d, np.abs(a - want).max() / scale, np.abs(b - want).max() / scale))
+            assert d < 1e-5, d
+            for g in (a, b):
+                mx, mean = np.abs(g - want).max() / scale, np.abs(g - want).mean() / scale
+                assert mx < POOL5_RTOL * 10 and mean < POOL5_RTOL
+                assert mx < POOL5_TIGHT_MAX and mean < POOL5_TIGHT_MEAN, ("regression bound", mx, mean)
+    finally:
+        resnet.set_winograd(True)
+    one = resnet.get_vec(xt[2:3].contiguous())       # 196 groups of 16: another grid, same rows
+    assert (one - resnet.get_vec(xt)[2:3]).abs().max().item() / scale < 1e-5
+
+
 def test_phasenet_winograd_layers_vs_direct_form(head, oracle, dev, monkeypatch):
     """PhaseNet's stride-1 3x3 layers with >= 64 input channels (88 -> 128 at 24x24 -- K padded to 128 with zero columns -- and
     128 -> 256 at 12x12) run through the fused F(4x4,3x3) kernel; MM_HEAD_WINOGRAD=0 keeps them in the direct implicit-GEMM form.
