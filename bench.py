@@ -584,6 +584,8 @@ def run_rank(args):
                 live.append((int(c_), float(w_), float(t_), tag_))
     except OSError:
         pass
+    import shutil
+    shutil.rmtree(os.path.dirname(dump_path), ignore_errors=True)
     conv_tflops = work_[0] / (ms[0] * 1e-3) / 1e12
     phase_ms = ms[1] + ms[2]
     phase_gbs = (work_[1] + work_[2]) / (phase_ms * 1e-3) / 1e9
