@@ -106,8 +106,13 @@ def test_default_line_has_the_contract_fields():
               "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert k in d, k
     assert "uint8" in d["config"]["workload"] and d["dtype"] == "f32" and d["vs_baseline"] is None
-    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "step_floor_ms", "mixed_frac", "mixed"):
         assert k in d["roofline"], k
+    # this run uses 4 clips per step: the committed PMC summaries are for the 32-clip step, so the PMC-derived fields are null
+    # here (and say why); the default 32-clip line carries them (tests/test_host_logic.py checks that profiles/ has the files)
+    assert d["roofline"]["mixed_frac"] is None and "note" in d["roofline"]["mixed"]
+    ph = d["roofline_phase"]
+    assert ph["floor_mfma_ms"] > ph["floor_hbm_ms"] > 0 and ph["limiting_floor"] == "mfma" and 0 < ph["frac_of_limiting_floor"] < 1
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["cpu_model"] and cb["deduplicated"]["value"] > 0
     ex = d["extra"]
