@@ -353,8 +353,7 @@ wino_fused_kernel(const WinoFusedParams p) {
                         Y[pp][qq][cb][e] = p.relu ? fmaxf(v, 0.f) : v;
                     }
         for (int pass = 0; pass < 4; ++pass) {
-            // (later passes: every wave is past its last read of the previous quarter; its stores are drained so that the counted
-            //  wait below sees only this pass's loads)
+            // (later passes: every wave is past its last read of the previous quarter)
             if (pass) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
             {
                 const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.w2) + (int64_t)pass * W2_FLOATS, 0,
@@ -378,7 +377,7 @@ wino_fused_kernel(const WinoFusedParams p) {
             };
             f32x4v rs[2][2], Pr[3][2];
             res_rows(rs[0], 0);
-            asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)\n\ts_barrier" ::: "memory");   // the matrix quarter landed (2 residual loads may still fly)
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");   // the matrix quarter (and position 0's residual rows) landed
 #pragma unroll
             for (int pos = 0; pos < 16; ++pos) {
                 const int pp = pos >> 2, qq = pos & 3;
@@ -481,7 +480,7 @@ wino_fused_kernel(const WinoFusedParams p) {
         };
         for (int pass = 0; pass < 2; ++pass) {
             // (second pass: every wave is past its last read of the first half)
-            // (vmcnt(0): the first pass's stores are drained, so the counted wait below sees only this pass's loads)
+            // (second pass: every wave is past its last read of the first half)
             if (pass) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
             {
                 const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.w2) + (int64_t)pass * W2_FLOATS, 0,
@@ -497,7 +496,7 @@ wino_fused_kernel(const WinoFusedParams p) {
             float* obase = p.out + pix0 * p.C2 + c0;
             f32x4v xs[2][4], Pr[2];
             x_rows(xs[0], 0);
-            asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory");   // the matrix half landed (the 4 x loads may still fly)
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");   // the matrix half (and position 0's x rows) landed
 #pragma unroll
             for (int pos = 0; pos < 16; ++pos) {
                 const int pp = pos >> 2, qq = pos & 3;
