@@ -76,7 +76,9 @@ def cpu_model():
 def _cpu_worker(first_clip, n_clips, threads, out_path, dedup):
     """One host process of the CPU baseline: the oracle on `n_clips` 64-frame clips with `threads` PyTorch threads.
     dedup=0: reference semantics incl. the 13x redundant pyramid (tester.py:122-139 on windowed input);
-    dedup=1: one pyramid per unique frame (variant ii).  Prints one JSON line with its timings."""
+    dedup=1: one pyramid per unique frame (BASELINE.md section 3, variant ii);
+    dedup=2: "as tuned" -- variant ii with the ResNet50 trunk on torch.channels_last tensors (same ops and arithmetic; oneDNN's NCHW
+    1x1 convolution, the reference's layout, is pathologically slow on AMD hosts).  Prints one JSON line with its timings."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import mm_oracle
     import mimamo_net_amd  # noqa: F401
@@ -99,7 +101,7 @@ def _cpu_worker(first_clip, n_clips, threads, out_path, dedup):
         else:
             p0, p1 = mm_oracle.phase_diff_output(gray[ids][None])       # tester.py:122-139 (windowed, 13x redundant)
         t1 = time.time()
-        feats = mm_oracle.resnet50_pool5(resnet_sd, rgb)                # resnet50_extractor.py:74-83
+        feats = mm_oracle.resnet50_pool5(resnet_sd, rgb, channels_last=dedup == 2)   # resnet50_extractor.py:74-83
         t2 = time.time()
         out = mm_oracle.two_stream_forward(head_sd, p0, p1, feats[None])  # mimamo_net.py:129-143
         t3 = time.time()
@@ -150,21 +152,38 @@ def cpu_baseline(n_clips, resnet_sd):
     procs = max(1, min(n_clips, (ncpu // 2) // best))      # physical cores (SMT pairs) / threads per process
     tmp = tempfile.mkdtemp(prefix="mm_cpu_")
     out0 = os.path.join(tmp, "clip0.npy")
-    v, wall, clips, recs = _cpu_run(n_clips, procs, best, False, out0)
-    v2, wall2, clips2, recs2 = _cpu_run(n_clips, procs, best, True, "")
+    v, wall, clips, recs = _cpu_run(n_clips, procs, best, 0, out0)
+    v2, wall2, clips2, recs2 = _cpu_run(n_clips, procs, best, 1, "")
+    v3, wall3, clips3, recs3 = _cpu_run(n_clips, procs, best, 2, "")
     cpu_out = np.load(out0)
 
     def stages(rs):
         return "phase %.1f s, resnet50 %.1f s, head %.1f s" % (np.mean([r["phase"] for r in rs]),
                                                                 np.mean([r["resnet"] for r in rs]), np.mean([r["head"] for r in rs]))
+
+    def stage_rates(rs):
+        """Per process (its `threads` cores): GFLOP/s of the ResNet50 trunk and of the head on the direct-form counts of SURVEY 8(d)
+        (7.712 / 0.396 GFLOP per frame), frames/s of the phase stage."""
+        fr = float(np.mean([r["frames"] for r in rs]))
+        return {"resnet50_GFLOP_per_s_per_process": fr * 7.712 / max(np.mean([r["resnet"] for r in rs]), 1e-9),
+                "head_GFLOP_per_s_per_process": fr * 0.396 / max(np.mean([r["head"] for r in rs]), 1e-9),
+                "phase_frames_per_s_per_process": fr / max(np.mean([r["phase"] for r in rs]), 1e-9)}
+    cfg = torch.__config__.show()
+    libs = "; ".join(l.strip(" -") for l in cfg.splitlines() if any(k in l for k in ("Math Kernel Library", "MKL-DNN", "OpenMP", "CPU capability")))
     return {"value": v, "unit": "frames/s", "cores": procs * best, "kind": "port", "cpu_model": cpu_model(),
-            "logical_cpus": ncpu,
+            "logical_cpus": ncpu, "torch": torch.__version__, "torch_cpu_libraries": libs,
             "sample": "%d clips x 64 frames in %d processes x %d threads, oracle/mm_oracle.py on PyTorch-CPU fp32 with the "
-                      "reference's semantics (13x redundant pyramid), %.1f s wall; per process: %s"
+                      "reference's semantics (13x redundant pyramid, NCHW tensors), %.1f s wall; per process: %s"
                       % (clips, procs, best, wall, stages(recs)),
+            "stage_rates": stage_rates(recs),
             "deduplicated": {"value": v2, "unit": "frames/s",
                              "sample": "same clips/processes/threads, one pyramid per unique frame, %.1f s wall; per process: %s"
-                                       % (wall2, stages(recs2))}}, cpu_out
+                                       % (wall2, stages(recs2))},
+            "as_tuned": {"value": v3, "unit": "frames/s", "stage_rates": stage_rates(recs3),
+                         "sample": "same clips/processes/threads, one pyramid per unique frame AND the ResNet50 trunk on "
+                                   "torch.channels_last tensors (same ops, same fp32 arithmetic: oneDNN's NCHW 1x1 convolution -- the "
+                                   "reference's layout -- is what the reference-faithful figure mostly measures on this host), "
+                                   "%.1f s wall; per process: %s" % (wall3, stages(recs3))}}, cpu_out
 
 
 # ---------------------------------------------------------------------------------------------------------
@@ -182,11 +201,6 @@ class HipCompute(object):
         self.resnet_sd = weights.make_resnet50_state_dict(seed=0)
         self.hot = HotPath(self.head_sd, self.resnet_sd, device)
         self.hot.resnet.set_winograd(0 if args.no_winograd else args.winograd)
-        if getattr(args, "lane_cus", ""):
-            from mimamo_net_amd.stream import parse_partitions
-            parts = parse_partitions(args.lane_cus)
-            self.hot.set_lane_partitions(parts)
-            args.lanes = len(parts)
         self.pool = {}          # clip content id -> row in the device-resident pool
         self.frames_u8 = None   # [P*64,112,112,3] uint8
         self.pre = None         # (gray, rgb) of the pool for --from-f32
@@ -287,7 +301,7 @@ class HipCompute(object):
 
     def _forward(self, ins, n_clips, lanes, u8):
         lengths = [FRAMES_PER_CLIP] * n_clips
-        if lanes > 1 or getattr(self.hot, "_lane_partitions", None):    # a single partitioned lane still runs on ITS stream
+        if lanes > 1:
             return self.hot.forward_lanes(ins, lengths, lanes, independent_clips=True, from_u8=u8)
         plan = self.hot.plan(lengths) if getattr(self, "_plan_n", None) != len(lengths) else self._plan
         self._plan, self._plan_n = plan, len(lengths)
@@ -354,9 +368,6 @@ def parse_args(argv=None):
     ap.add_argument("--no-winograd", action="store_true", help="run every 3x3 layer in the direct implicit-GEMM form")
     ap.add_argument("--winograd", type=int, default=1, help="1 = default (F(4x4,3x3); conv2_x..conv4_x with the output transform fused into the position GEMMs), 2 = F(2x2,3x3), 4 = F(4x4,3x3) as three kernels everywhere, 5 = fused everywhere")
     ap.add_argument("--lanes", type=int, default=3, help="HIP streams the clips of a step are spread over (1 = single stream)")
-    ap.add_argument("--lane-cus", default=os.environ.get("MM_LANE_CUS", ""),
-                    help="measurement: confine lane i to a CU subset, e.g. '0-127/128-255' (two half-chip lanes); implies --lanes = "
-                         "number of subsets.  Default: ordinary streams")
     ap.add_argument("--from-f32", action="store_true",
                     help="start every step from host-preprocessed fp32 tensors (gray 48x48, RGB 224x224) instead of the "
                          "raw uint8 boundary")
@@ -404,7 +415,11 @@ def run_rank(args):
     init_s = time.perf_counter() - t_init
     # host side of a rank: its threads stay on the CPUs next to its GPU (NUMA node from sysfs; an even slice of the allowed CPUs
     # when the platform does not say).  N = 1 stays unbound: rank 0 alone runs the cpu_baseline on the whole host.
-    cpu_bind = mdist.bind_rank_cpus(local_rank, world, ([0] * world if args.same_device else list(range(world))) if gpu else None) \
+    # the ranks of THIS node (LOCAL_WORLD_SIZE from the launcher; one node = the whole job): a multi-node launch must not split the
+    # node's CPUs by the global world size or probe device indices that live on other nodes
+    local_world = max(1, min(world, int(os.environ.get("LOCAL_WORLD_SIZE", world))))
+    cpu_bind = mdist.bind_rank_cpus(local_rank, local_world,
+                                    ([0] * local_world if args.same_device else list(range(local_world))) if gpu else None) \
         if world > 1 and not args.no_cpu_bind else {"numa_node": None, "cpus": len(os.sched_getaffinity(0)), "first_cpu": -1, "bound": False}
     if gpu:
         torch.cuda.set_device(dev_index)
@@ -637,7 +652,9 @@ def run_rank(args):
             return {"step_floor_ms": floor, "measured_ms": meas, "mixed_frac": floor / meas, "launches": len(live),
                     "mfma_bound_launches": {"floor_ms": by_bound["mfma"][0], "measured_ms": by_bound["mfma"][1]},
                     "hbm_bound_launches": {"floor_ms": by_bound["hbm"][0], "measured_ms": by_bound["hbm"][1]},
-                    "bytes_file": os.path.basename(path)}, None
+                    "bytes_source": "committed PMC bytes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE per launch, not live); times and FLOPs live",
+                    "bytes_file": os.path.basename(path), "bytes_file_kernel_source_hash": lb.get("kernel_source_hash"),
+                    "bytes_file_mtime": time.strftime("%Y-%m-%d", time.gmtime(os.path.getmtime(path)))}, None
         return None, "no per-launch PMC byte list under profiles/ for these kernel sources (hash %s)" % kernel_source_hash()
 
     mixed, mixed_note = mixed_roofline() if live else (None, "no per-launch dump")
@@ -751,7 +768,76 @@ def extra_legs(args, comp, ids0, n_frames):
                                    "snippets; unique frames counted once (snippet rows: %d per video)"
                                    % (len(plan["videos"][0]["ranges"]) * plan["videos"][0]["T"])}
     del vids
+    # (c) per-stage rates for the other single-GPU BASELINE configurations (SURVEY 8(d) "also per-stage frames/s")
+    ex["phase_only"] = phase_only_leg(comp)
+    ex["resnet50_only"] = resnet50_only_leg(comp)
     return ex
+
+
+def _time_stream(fn, budget_s=1.0, min_iters=3):
+    """Mean seconds per call on the current stream: warm-up call, then as many calls as fit `budget_s` (at least min_iters),
+    bracketed by device synchronisation."""
+    fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    fn()
+    torch.cuda.synchronize()
+    one = max(time.perf_counter() - t0, 1e-5)
+    iters = max(min_iters, min(200, int(budget_s / one)))
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / iters, iters
+
+
+def phase_only_leg(comp):
+    """BASELINE configs[1]: steerable pyramid + phase difference only, 64-frame clips, one stream.  Input = the gray 48x48 fp32
+    frames (the pyramid's input, api/phase_difference_extractor.py:38; from the bench's textured clips -- the wrap rate matters:
+    the window kernel skips blurs until a window's first wrap), output = phase_0 [N,48,48,24] + phase_1 into PhaseNet's concat buffer,
+    i.e. exactly the phase stage of the full step."""
+    from mimamo_net_amd import sampler
+    hot, dev = comp.hot, comp.device
+    if hot._pre is None:
+        from mimamo_net_amd.preprocess import FramePreprocessor
+        hot._pre = FramePreprocessor(phase_size=hot.phase_size, mean=hot.resnet.meta['mean'], device=dev)
+    out = {"unit": "frames/s", "algorithmic_bytes_per_frame": 285696,
+           "what": "pyramid_frame_kernel + phase_window2_kernel<48|24> on gray 48x48 fp32 frames resident in HBM, 13-frame clamped windows "
+                   "of 64-frame clips, single stream (BASELINE configs[1]); GB_per_s on SURVEY 8(d)'s 285 696 B/frame"}
+    pool_clips = comp.frames_u8.shape[0] // FRAMES_PER_CLIP
+    with torch.no_grad():
+        gray_pool = hot._pre(comp.frames_u8, want_rgb=False)[0]
+        for clips in (32, 256):
+            n = clips * FRAMES_PER_CLIP
+            reps = (clips + pool_clips - 1) // pool_clips
+            gray = gray_pool.repeat(reps, 1, 1)[:n].contiguous()
+            ids = torch.from_numpy(np.concatenate([sampler.window_ids(0, FRAMES_PER_CLIP, FRAMES_PER_CLIP) + FRAMES_PER_CLIP * c
+                                                   for c in range(clips)]).astype(np.int32)).to(dev)
+            dt, iters = _time_stream(lambda: hot.pde.phase_diff_frames(gray, ids, nhwc=True, out1_cstride=88, out1_coffset=64,
+                                                                       ids_checked=True), 0.6)
+            out["clips_%d" % clips] = {"value": n / dt, "ms_per_pass": dt * 1e3, "frames": n, "iters": iters,
+                                       "GB_per_s": n * 285696 / dt / 1e9, "frac_of_hbm_peak": n * 285696 / dt / 1e9 / PEAK_HBM_GBS}
+            del gray, ids
+    return out
+
+
+def resnet50_only_leg(comp):
+    """BASELINE configs[2]: ResNet50 pool5 extractor on synthetic 224x224 face batches, fp32 [B,3,224,224] in the reference's NCHW
+    layout resident in HBM (the layout conversion is part of the call), batch 64 (the reference's `run()` batch,
+    api/resnet50_extractor.py:42) and 256, single stream."""
+    hot, dev = comp.hot, comp.device
+    out = {"unit": "frames/s", "algorithmic_flops_per_frame": 7.712e9,
+           "what": "Resnet50_Extractor.get_vec on fp32 [B,3,224,224] (255*x - mean) resident in HBM, single stream (BASELINE configs[2]); "
+                   "TFLOP_per_s on SURVEY 8(d)'s direct-form 7.712 GFLOP/frame (Winograd executes fewer)"}
+    with torch.no_grad():
+        for bs in (64, 256):
+            x = (torch.rand((bs, 3, 224, 224), device=dev) * 255.0 - 110.0).contiguous()
+            dt, iters = _time_stream(lambda: hot.resnet.get_vec(x), 1.0)
+            out["batch_%d" % bs] = {"value": bs / dt, "ms_per_batch": dt * 1e3, "iters": iters,
+                                    "TFLOP_per_s_algorithmic": bs * 7.712e9 / dt / 1e12,
+                                    "frac_of_fp32_mfma_peak_algorithmic": bs * 7.712e9 / dt / 1e12 / PEAK_FP32_MFMA_TFLOPS}
+            del x
+    return out
 
 
 if __name__ == "__main__":

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define MM_VERSION 104 /* 0.1.4: round 4 adds mm_stream_create_cu_mask / mm_stream_get_cu_mask / mm_stream_destroy */
+#define MM_VERSION 105 /* 0.1.5: round 5 removes the CU-mask stream entry points of 0.1.4 (measured null, never used by the product path) */
 
 typedef enum mm_status {
     MM_OK = 0,
@@ -267,16 +267,6 @@ int mm_preproc_forward(mm_preproc_t* h, const uint8_t* frames, int64_t n, float*
 #define MM_PROF_CATEGORIES 5
 int mm_profile_begin(void);
 int mm_profile_end(double* ms, double* work, int64_t* launches);
-
-/* ---------------------------------------------------------------------------------------
- * CU-partitioned streams (no reference counterpart: the reference uses torch's default stream only,
- * api/steerable/utils.py:34-50).  A stream whose kernels may only run on the CUs whose bit is set in `mask`
- * (bit i of word i/32; on a multi-XCD part consecutive bits go round-robin over the XCDs, so a prefix of 8k bits is k CUs on
- * every XCD).  Every mm_* entry point takes such a stream like any other.  An all-zero mask is MM_ERR_INVALID_ARG.
- * ------------------------------------------------------------------------------------- */
-int mm_stream_create_cu_mask(void** stream, const uint32_t* mask, int words);
-int mm_stream_get_cu_mask(void* stream, uint32_t* mask, int words);
-int mm_stream_destroy(void* stream);
 
 #ifdef __cplusplus
 }

@@ -61,9 +61,6 @@ SIGNATURES = {
     "mm_head_destroy": (_i, [_vp]),
     "mm_head_workspace_bytes": (_i64, [_vp, _i64, _i64]),
     "mm_head_forward": (_i, [_vp, _vp, _vp, _i, _vp, _i64, _i64, _vp, _vp, _i64, _vp]),
-    "mm_stream_create_cu_mask": (_i, [_c.POINTER(_vp), _c.POINTER(_c.c_uint32), _i]),
-    "mm_stream_get_cu_mask": (_i, [_vp, _c.POINTER(_c.c_uint32), _i]),
-    "mm_stream_destroy": (_i, [_vp]),
 }
 
 _lib = None

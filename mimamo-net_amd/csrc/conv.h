@@ -43,7 +43,8 @@ int nchw_to_nhwc(const float* in, float* out, int64_t N, int C, int HW, int cstr
 int nchw3_to_bordered_nhwc3(const float* in, float* out, int64_t N, int S, int pad, hipStream_t s);
 // MaxPool2d(k=3, s=2, pad=0, ceil_mode) on NHWC
 int maxpool3x3s2(const float* in, float* out, int64_t N, int H, int W, int C, int Ho, int Wo, hipStream_t s);
-// the same pool AND the 1x1 conv that follows it at conv2_1 (64 -> 64, w [64][64] BN-folded, + bias, ReLU) in one kernel (pool_reduce.hip):
+// the same pool AND the 1x1 conv that follows it at conv2_1 (64 -> 64, w [64][64] BN-folded, + bias, ReLU) in one kernel (pool_reduce.hip;
+// the pooled values reach the MFMA through a wave-private LDS stage):
 // x_out = the pooled tensor (bit-identical to maxpool3x3s2), y_out = relu?(w x + bias); NHWC, 64 channels
 int maxpool_reduce64(const float* in, const float* w, const float* bias, float* x_out, float* y_out, int64_t N, int H, int W, int Ho, int Wo,
                      int relu, hipStream_t s);
@@ -62,8 +63,9 @@ int wino_output_transform(const float* M, const float* bias, float* y, int B, in
 // Needs Cin % 64 == 0 and Cout % 32 == 0 (MM_ERR_UNSUPPORTED otherwise).
 int wino_gemm_output_fused(const float* V, const float* U, const float* bias, float* y, int B, int H, int W, int Cin, int Cout,
                            int relu, int shape, hipStream_t s);
-// The same kernel with the residual block's 1x1 increase conv inside its epilogue (Cout == 64, C2 == 256: conv2_x blocks 2, 3):
-// out [B,H,W,C2] = relu( W2 relu(conv3x3(x) + bias) + bias2 + res ); the 64-channel tensor in between never reaches HBM.
+// The same kernel with the residual block's 1x1 increase conv inside its epilogue -- (Cout, C2) == (64, 256): conv2_x blocks 2, 3, or
+// (128, 512): conv3_x blocks 2-4 (eight-wave workgroup):
+// out [B,H,W,C2] = relu( W2 relu(conv3x3(x) + bias) + bias2 + res ); the Cout-channel tensor in between never reaches HBM.
 int wino_gemm_output_fused_inc(const float* V, const float* U, const float* bias, const float* W2, const float* bias2, const float* res,
                                float* out, int B, int H, int W, int Cin, int Cout, int C2, int relu, hipStream_t s);
 bool wino_fused_inc_supported(int64_t ntile, int Cin, int Cout, int C2);

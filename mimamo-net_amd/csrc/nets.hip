@@ -211,8 +211,8 @@ static int run_layer_dual(const Layer& L, const float* in, int B, int H, int W, 
     return conv_forward(p, s);
 }
 
-static int g_wino_fused_max_cin = 256;   // measurement knob (MM_WF_MAX_CIN)
-static int g_wino_fused_shape = 0;   // measurement knob (MM_WINO_FUSED_SHAPE): workgroup shape of the fused kernel, 0 = auto
+static int g_wino_fused_max_cin = 256;   // fused kernel for Cin <= this (conv5_x stays on the three-kernel form); -DMM_MEASURE builds: MM_WF_MAX_CIN
+static int g_wino_fused_shape = 0;       // workgroup shape of the fused kernel, 0 = auto; -DMM_MEASURE builds: MM_WINO_FUSED_SHAPE
 
 // inc / inc_res / inc_out (optional, fused form only): the residual block's increase layer applied inside the fused kernel --
 // inc_out [B,H,W,inc->cout] = relu(inc(relu(L(in))) + inc_res); `out` is then not written.  Returns MM_ERR_UNSUPPORTED (before
@@ -231,8 +231,9 @@ static int run_layer_wino(const Layer& L, const float* in, int B, int H, int W, 
     if (wc != L.cin_p && m != 4) return MM_ERR_UNSUPPORTED;
     // no plane set for the three-kernel form and the fused kernel declines the shape: say so before transforming anything
     if (!M && !(fused && wino_fused_supported(ntile, wc, L.cout))) return MM_ERR_UNSUPPORTED;
+    // (the two-source form exists for Cout == 64 only: decline here, before the input transform is launched)
     if (inc && !(fused && inc->k == 1 && inc->stride == 1 && inc->Kpad == (inc_two_src ? 2 : 1) * L.cout && inc->korder == 0 && inc->relu &&
-                 !inc->ps && wino_fused_inc_supported(ntile, wc, L.cout, inc->cout)))
+                 !inc->ps && (!inc_two_src || L.cout == 64) && wino_fused_inc_supported(ntile, wc, L.cout, inc->cout)))
         return MM_ERR_UNSUPPORTED;
     int rc = wino_input_transform(in, V, B, H, W, wc, m, s, L.cin_p);
     if (rc != MM_OK) return rc;
@@ -292,7 +293,8 @@ struct mm_resnet50 {
     int winograd;  // 0 direct, 2 = F(2x2,3x3), 4 = F(4x4,3x3) for the layers that have Winograd-domain weights
     int fuse_proj; // 1 (default): the first block of a stage runs increase + projection as one launch
     int fuse_pool; // 1 (default): pool1 and conv2_1's 1x1 reduce conv run as one kernel (pool_reduce.hip)
-    int fuse_inc;  // 1 (default): conv2_x blocks without a projection run 3x3 + increase + residual in ONE kernel (wino_fused.hip INC)
+    int fuse_inc;  // 3x3 + increase conv (+ residual | + projection) in ONE kernel (wino_fused.hip INC): 0 = never (the parity twin), 1 = conv2_x
+                   // blocks 2-3, 2 = also conv2_x block 1 (increase | projection over two K sources), 3 (default) = also conv3_x blocks 2-4
     int device;
 };
 
@@ -424,10 +426,12 @@ int mm_resnet50_create(mm_resnet50_t** out, const float* blob, int64_t n_floats,
         rc = make_layer(h->arena, h->stem3, w, nullptr, 64, 3, 7, 2, 0, 1, &bn, nullptr, bn_eps, false, true);
     }
     conv_bn(h->stem, 64, 3, 7, 2, 3, 1);
-    if (const char* st = getenv("MM_STEM_TILE")) {   // measurement knob: 1 = 128x128, 2 = 128x64 (automatic choice), 3 = 64x64, 4 = 256x64
+#ifdef MM_MEASURE
+    if (const char* st = getenv("MM_STEM_TILE")) {   // measurement builds only: 1 = 128x128, 2 = 128x64 (automatic choice), 3 = 64x64, 4 = 256x64
         const int t = atoi(st);
         if (t >= 0 && t <= 4) h->stem.tile = h->stem3.tile = t;
     }
+#endif
     int cin = 64;
     for (auto& st : kStages)
         for (int b = 0; b < st[0]; ++b) {
@@ -479,10 +483,12 @@ int mm_resnet50_set_winograd(mm_resnet50_t* h, int enable) {
     if (!h) return MM_ERR_INVALID_ARG;
     if (enable != 0 && enable != 1 && enable != 2 && enable != 4 && enable != 5) return MM_ERR_INVALID_ARG;
     h->winograd = enable;   // 1 = default: F(4x4,3x3), output transform fused into the GEMMs where that is faster (Cin <= 256)
-    const char* mc = getenv("MM_WF_MAX_CIN");
+#ifdef MM_MEASURE
+    const char* mc = getenv("MM_WF_MAX_CIN");         // measurement builds only (tuning sweeps of rounds 2-4)
     if (mc) mm::g_wino_fused_max_cin = atoi(mc);
     const char* sh = getenv("MM_WINO_FUSED_SHAPE");
     mm::g_wino_fused_shape = sh ? atoi(sh) : 0;
+#endif
     return MM_OK;
 }
 

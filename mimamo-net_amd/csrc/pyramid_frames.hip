@@ -419,7 +419,11 @@ int launch_pyramid_frames(const mm_pyramid* h, const float* frames, int64_t n, f
     const int lds_bytes = pf::L_TOTAL * 4 + lds_pad;
     MM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(pf::pyramid_frame_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                lds_bytes));
+#ifdef MM_MEASURE
     static const int grid_cap = getenv("MM_PF_GRID") ? atoi(getenv("MM_PF_GRID")) : 2048;
+#else
+    constexpr int grid_cap = 2048;
+#endif
     int64_t grid = n;
     if (grid > grid_cap) grid = grid_cap;   // 256 CUs x 2 resident workgroups x 4 rounds; the rest grid-strides (tables stay in LDS)
     prof_before(1, (double)n * (pyr::S * pyr::S * 4), stream, "pyramid_frame");   // algorithmic read of the stage: one fp32 frame

@@ -26,8 +26,10 @@ class HotPath(object):
 
     def __init__(self, head_state_dict, resnet_state_dict, device=None, length=64, stride=64, num_phase=12,
                  batch_size=64, max_frames_per_call=4096, upload_chunk_frames=1024, phase_size=48, height=4, nbands=2,
-                 scale_factor=2, extract_level=(1, 2), model_num_phase=12):
-        """model_num_phase: num_phase of the Two_Stream_RNN the checkpoint belongs to.  The reference's Tester always builds
+                 scale_factor=2, extract_level=(1, 2), model_num_phase=12, resnet_kwargs=None):
+        """resnet_kwargs: further Resnet50_Extractor keywords (benchmark_dir / model_name: where a model definition file may sit;
+        stride_on_first_1x1, ceil_mode, bn_eps, mean).
+        model_num_phase: num_phase of the Two_Stream_RNN the checkpoint belongs to.  The reference's Tester always builds
         Two_Stream_RNN() with its default (api/tester.py:44), whatever num_phase its sampler uses -- so a non-published
         sampler / pyramid configuration only runs there (and here) when it still hands PhaseNet 24 channels at 48x48 and
         24x24, e.g. nbands=4 with num_phase=6."""
@@ -43,7 +45,7 @@ class HotPath(object):
         self._feeders = {}
         self.pde = Phase_Difference_Extractor(height, nbands, scale_factor, list(levels) if len(levels) > 1 else levels[0], False)
         self.resnet = Resnet50_Extractor(state_dict=resnet_state_dict, device=self.device,
-                                         max_frames_per_call=self.max_frames_per_call)
+                                         max_frames_per_call=self.max_frames_per_call, **(resnet_kwargs or {}))
         self.head = Two_Stream_RNN(num_phase=model_num_phase).load_state_dict(head_state_dict).eval().to(self.device)
         self._pre = None
 
@@ -128,7 +130,7 @@ class HotPath(object):
         self._check(plan, frames_u8.shape[0], independent_clips)
         if self._pre is None:
             from .preprocess import FramePreprocessor
-            self._pre = FramePreprocessor(phase_size=self.phase_size, device=self.device)
+            self._pre = FramePreprocessor(phase_size=self.phase_size, mean=self.resnet.meta['mean'], device=self.device)
         if not frames_u8.is_cuda:
             if not frames_u8.is_pinned():
                 # a pageable source makes every non_blocking copy synchronous with the host: nothing would overlap
@@ -254,16 +256,12 @@ class HotPath(object):
         _, plans, frs = cache
         # one persistent pool of side streams: per-stream workspaces (Resnet50_Extractor) are keyed by stream, so new
         # streams for every new (lengths, lanes) combination would strand tens of GB of workspace each
-        parts = getattr(self, "_lane_partitions", None)
-        if parts is not None and len(parts) >= lanes:
-            streams = [p.stream for p in parts[:lanes]]            # CU-partitioned lanes (set_lane_partitions)
-        else:
-            pool = getattr(self, "_lane_streams", None)
-            if pool is None:
-                pool = self._lane_streams = []
-            while len(pool) < lanes:
-                pool.append(torch.cuda.Stream(device=self.device))
-            streams = pool[:lanes]
+        pool = getattr(self, "_lane_streams", None)
+        if pool is None:
+            pool = self._lane_streams = []
+        while len(pool) < lanes:
+            pool.append(torch.cuda.Stream(device=self.device))
+        streams = pool[:lanes]
         cur = torch.cuda.current_stream()
         outs = []
         for plan, (f0, f1), st in zip(plans, frs, streams):
@@ -276,17 +274,6 @@ class HotPath(object):
         for st in streams:
             cur.wait_stream(st)
         return torch.cat(outs, 0)
-
-    def set_lane_partitions(self, cu_lists):
-        """Confine the lanes of forward_lanes to CU subsets: cu_lists[i] = CU indices lane i may use (stream.PartitionStream), or
-        None to go back to ordinary streams.  Measurement lever of round 4: an HBM-bound kernel holds the full
-        bandwidth on half the chip, so two half-chip lanes leave the other half to the other lane's GEMMs."""
-        from .stream import PartitionStream
-        old = getattr(self, "_lane_partitions", None)
-        self._lane_partitions = None if not cu_lists else [PartitionStream(c, self.device) for c in cu_lists]
-        if old:
-            for p in old:
-                p.close()
 
     def assemble(self, out_rows, plan, label_name=('valence', 'arousal')):
         """[rows,2] -> {video index: float64 [n_frames,2]} with the reference's overwrite order."""

@@ -17,8 +17,16 @@ from . import _lib, weights
 
 class Resnet50_Extractor(object):
     def __init__(self, benchmark_dir='pytorch-benchmarks', model_name='resnet50_ferplus_dag',
-                 feature_layer='pool5_7x7_s1', state_dict=None, device=None, max_frames_per_call=4096):
+                 feature_layer='pool5_7x7_s1', state_dict=None, device=None, max_frames_per_call=4096,
+                 stride_on_first_1x1=None, ceil_mode=None, bn_eps=None, mean=None):
         """benchmark_dir/model_name/feature_layer as api/resnet50_extractor.py:14-15.
+
+        stride_on_first_1x1 / ceil_mode / bn_eps / mean: the parts of the third-party graph the reference's own code does not
+        pin: stride 2 of a stage's first block on its 1x1 reduce conv (Caffe style, True) or on its 3x3 conv
+        (False); `pool1_3x3_s2` with ceil_mode (112 -> 56) or floor (-> 55); BatchNorm eps; `meta['mean']`.  None = what the model
+        definition file `<benchmark_dir>/ferplus/<model_name>.py` says when it exists (the file the reference executes,
+        api/utils/model_utils.py:65-79; read with `ast`, see weights.read_model_definition), else the published model's values
+        (True, True, 1e-5, weights.RESNET50_MEAN).
 
         state_dict: weights in the third-party key layout.  If None, `<benchmark_dir>/ferplus/<model_name>.pth`
         is loaded when it exists (the reference's location, api/resnet50_extractor.py:35-36); otherwise the
@@ -36,13 +44,28 @@ class Resnet50_Extractor(object):
             assert os.path.exists(self.benchmark_dir), 'benchmark_dir must exits'
             pth = os.path.join(self.benchmark_dir, 'ferplus', model_name + '.pth')
             state_dict = torch.load(pth, map_location='cpu')
+        definition = {}
+        def_path = os.path.join(self.benchmark_dir, 'ferplus', model_name + '.py')
+        if os.path.isfile(def_path):
+            definition = weights.read_model_definition(def_path)
+        pick = lambda given, key, default: given if given is not None else definition.get(key, default)   # noqa: E731
+        self.stride_on_first_1x1 = bool(pick(stride_on_first_1x1, 'stride_on_first_1x1', True))
+        self.ceil_mode = bool(pick(ceil_mode, 'ceil_mode', True))
+        self.bn_eps = float(pick(bn_eps, 'bn_eps', 1e-5))
         self.meta = {'mean': list(weights.RESNET50_MEAN), 'std': [1, 1, 1], 'imageSize': [224, 224, 3]}
+        self.meta.update(definition.get('meta', {}))
+        if mean is not None:
+            self.meta['mean'] = [float(m) for m in mean]
+        if list(self.meta['std']) != [1, 1, 1] or list(self.meta['imageSize'])[:2] != [224, 224] or len(self.meta['mean']) != 3:
+            # compose_transforms (api/utils/model_utils.py:26-39) would scale / crop differently; the GPU preprocessing is built for this one
+            raise NotImplementedError("model meta %r: only std [1,1,1] and imageSize 224 are implemented" % (self.meta,))
         self.device = torch.device('cuda', torch.cuda.current_device()) if device is None else torch.device(device)
         blob = weights.resnet50_blob(state_dict)
         h = ctypes.c_void_p()
         L = _lib.lib()
         with torch.cuda.device(self.device):
-            rc = L.mm_resnet50_create(ctypes.byref(h), blob.ctypes.data_as(ctypes.c_void_p), blob.size, 1, 1, 1e-5)
+            rc = L.mm_resnet50_create(ctypes.byref(h), blob.ctypes.data_as(ctypes.c_void_p), blob.size,
+                                      int(self.stride_on_first_1x1), int(self.ceil_mode), self.bn_eps)
         _lib.check(rc, "mm_resnet50_create")
         self._handle = h
         self._ws = {}   # per-stream workspaces: the handle itself is stateless, so lanes on different streams may share it

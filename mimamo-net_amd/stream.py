@@ -22,57 +22,6 @@ def pin(array):
     return t if t.is_pinned() else t.pin_memory()
 
 
-class PartitionStream(object):
-    """A HIP stream whose kernels may only run on the CUs listed in `cus` (mm_stream_create_cu_mask; bit order = the runtime's:
-    consecutive indices go round-robin over the XCDs, so range(0, 128) is 16 CUs on each of the 8 XCDs).  `.stream` is a
-    torch.cuda.ExternalStream usable like any other torch stream; the HIP stream lives as long as this object."""
-
-    def __init__(self, cus, device=None):
-        import ctypes
-        from . import _lib
-        self.device = torch.device('cuda', torch.cuda.current_device()) if device is None else torch.device(device)
-        ncu = torch.cuda.get_device_properties(self.device).multi_processor_count
-        cus = sorted(set(int(c) for c in cus))
-        if not cus or cus[0] < 0 or cus[-1] >= ncu:
-            raise ValueError("CU indices must be in [0, %d)" % ncu)
-        words = (ncu + 31) // 32
-        mask = (ctypes.c_uint32 * words)()
-        for c in cus:
-            mask[c // 32] |= 1 << (c % 32)
-        self._h = ctypes.c_void_p()
-        with torch.cuda.device(self.device):
-            _lib.check(_lib.lib().mm_stream_create_cu_mask(ctypes.byref(self._h), mask, words), "mm_stream_create_cu_mask")
-        self.cus = cus
-        self.stream = torch.cuda.ExternalStream(self._h.value, device=self.device)
-
-    def close(self):
-        if getattr(self, "_h", None) is not None and self._h.value:
-            from . import _lib
-            self.stream.synchronize()
-            _lib.lib().mm_stream_destroy(self._h)
-            self._h = None
-
-    def __del__(self):
-        try:
-            self.close()
-        except Exception:
-            pass
-
-
-def parse_partitions(spec):
-    """"0-127/128-255" -> [[0..127], [128..255]]; "0-63,128-191/..." unions ranges inside a lane; "" -> None."""
-    if not spec:
-        return None
-    lanes = []
-    for part in spec.split("/"):
-        cus = []
-        for r in part.split(","):
-            a, _, b = r.partition("-")
-            cus += list(range(int(a), int(b or a) + 1))
-        lanes.append(cus)
-    return lanes
-
-
 class FrameStream(object):
     def __init__(self, device, frames_per_slot, frame_shape=(112, 112, 3), depth=2, dtype=torch.uint8):
         self.device = torch.device(device)

@@ -42,7 +42,8 @@ class Tester(object):
             assert os.path.exists(pth), 'benchmark_dir must exits'
             resnet_state_dict = torch.load(pth, map_location='cpu')
         self.hot = HotPath(head_state_dict, resnet_state_dict, device, length, stride, num_phase, batch_size, phase_size=phase_size,
-                           height=height, nbands=nbands, scale_factor=scale_factor, extract_level=tuple(extract_level))
+                           height=height, nbands=nbands, scale_factor=scale_factor, extract_level=tuple(extract_level),
+                           resnet_kwargs=dict(benchmark_dir=benchmark_dir, model_name=model_name, feature_layer=feature_layer))
         self.device = self.hot.device
         self.phase_difference_extractor = self.hot.pde
         self.resnet50_extractor = self.hot.resnet

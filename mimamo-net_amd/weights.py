@@ -168,17 +168,85 @@ def _np(v):
 
 
 def resnet50_blob(state_dict):
-    """Per layer of resnet50_layers(): conv weight (OIHW), then BN weight, bias, running_mean, running_var."""
+    """Per layer of resnet50_layers(): conv weight (OIHW), then BN weight, bias, running_mean, running_var.
+
+    A conv bias b (the published model file declares `bias=False` everywhere, but a re-exported checkpoint may carry one) is
+    folded into the BatchNorm that follows: BN(conv + b) = gamma * (conv - (mean - b)) / sqrt(var + eps) + beta, i.e. the blob's
+    running_mean is mean - b (float64, rounded once)."""
     parts = []
     for name, cin, cout, k, _, _ in resnet50_layers():
         w = _np(state_dict[name + ".weight"])
         assert w.size == cout * cin * k * k, name
-        if (name + ".bias") in state_dict:
-            raise NotImplementedError("conv bias in the ResNet50 trunk (the third-party model has none)")
         parts.append(w)
         for s in ("weight", "bias", "running_mean", "running_var"):
-            parts.append(_np(state_dict[name + "_bn." + s]))
+            v = _np(state_dict[name + "_bn." + s])
+            assert v.size == cout, name + "_bn." + s
+            if s == "running_mean" and state_dict.get(name + ".bias") is not None:
+                b = _np(state_dict[name + ".bias"])
+                assert b.size == cout, name + ".bias"
+                v = (v.astype(np.float64) - b.astype(np.float64)).astype(np.float32)
+            parts.append(v)
     return np.concatenate(parts)
+
+
+def read_model_definition(py_path):
+    """What the third-party model DEFINITION file next to the weights says about the graph, without executing it.
+
+    The reference executes `<benchmark_dir>/ferplus/<model_name>.py` and instantiates its class (api/utils/model_utils.py:65-79),
+    then reads `model.meta` (api/resnet50_extractor.py:38-41).  Those generated files are flat lists of
+    `self.<layer> = nn.<Type>(...)` assignments plus `self.meta = {...}`; this reads them with `ast` (literals only):
+      meta                 {'mean', 'std', 'imageSize'} when the file assigns a literal dict to `self.meta`
+      stride_on_first_1x1  True when `conv3_1_1x1_reduce` has stride 2 (Caffe style), False when `conv3_1_3x3` has it
+      ceil_mode            `pool1_3x3_s2`'s ceil_mode
+      bn_eps               eps of `conv1_7x7_s2_bn`
+    Keys the file does not settle are absent from the result."""
+    import ast
+    with open(py_path, "r") as f:
+        tree = ast.parse(f.read(), filename=py_path)
+
+    def lit(node):
+        try:
+            return ast.literal_eval(node)
+        except Exception:
+            return None
+
+    layers, out = {}, {}
+    for node in ast.walk(tree):
+        if not isinstance(node, ast.Assign) or len(node.targets) != 1:
+            continue
+        t = node.targets[0]
+        if not (isinstance(t, ast.Attribute) and isinstance(t.value, ast.Name) and t.value.id == "self"):
+            continue
+        if t.attr == "meta":
+            m = lit(node.value)
+            if isinstance(m, dict) and "mean" in m:
+                out["meta"] = {k: (list(v) if isinstance(v, (list, tuple)) else v) for k, v in m.items()}
+        elif isinstance(node.value, ast.Call):
+            fn = node.value.func
+            kind = fn.attr if isinstance(fn, ast.Attribute) else getattr(fn, "id", None)
+            kw = {k.arg: lit(k.value) for k in node.value.keywords if k.arg}
+            layers[t.attr] = (kind, [lit(a) for a in node.value.args], kw)
+
+    def stride_of(name):
+        if name not in layers or layers[name][0] != "Conv2d":
+            return None
+        _, args, kw = layers[name]
+        s = kw.get("stride", args[3] if len(args) > 3 else 1)
+        if isinstance(s, (list, tuple)):
+            s = s[0]
+        return int(s) if s is not None else None
+
+    s1, s3 = stride_of("conv3_1_1x1_reduce"), stride_of("conv3_1_3x3")
+    if s1 is not None and s3 is not None and {s1, s3} == {1, 2}:
+        out["stride_on_first_1x1"] = s1 == 2
+    if layers.get("pool1_3x3_s2", (None,))[0] == "MaxPool2d" and layers["pool1_3x3_s2"][2].get("ceil_mode") is not None:
+        out["ceil_mode"] = bool(layers["pool1_3x3_s2"][2]["ceil_mode"])
+    if layers.get("conv1_7x7_s2_bn", (None,))[0] == "BatchNorm2d":
+        _, args, kw = layers["conv1_7x7_s2_bn"]
+        eps = kw.get("eps", args[1] if len(args) > 1 else None)
+        if eps is not None:
+            out["bn_eps"] = float(eps)
+    return out
 
 
 _FLOAT_KEYS = {}

@@ -477,15 +477,21 @@ def resnet50_layer_list(stride_on_first_1x1=True):
     return layers
 
 
-def resnet50_pool5(state_dict, x, stride_on_first_1x1=True, ceil_mode=True, eps=1e-5, dtype=np.float32):
+def resnet50_pool5(state_dict, x, stride_on_first_1x1=True, ceil_mode=True, eps=1e-5, dtype=np.float32, channels_last=False):
     """Forward to `pool5_7x7_s1` and relu(squeeze) (resnet50_extractor.py:74-83).
 
     x [B,3,224,224] (already 255*x - mean) -> [B,2048].  Conv -> BN(eval) -> ReLU, bottleneck
     residual add then ReLU, MaxPool 3x3 s2 pad 0 ceil_mode, AvgPool 7x7.
+    channels_last: the same ops on torch.channels_last tensors (bench.py's "as tuned" CPU figure: on AMD hosts oneDNN's NCHW 1x1
+    convolution -- the reference's layout -- runs two orders of magnitude below its channels-last path); the reference itself
+    uses the default NCHW format (False).
     """
     tdt = torch.float32 if dtype == np.float32 else torch.float64
     sd = _to_torch_sd(state_dict, tdt)
     x = torch.from_numpy(np.ascontiguousarray(x)).to(tdt)
+    if channels_last:
+        x = x.contiguous(memory_format=torch.channels_last)
+        sd = {k: (v.contiguous(memory_format=torch.channels_last) if v.dim() == 4 else v) for k, v in sd.items()}
 
     def cbr(x, name, stride, pad, relu=True):
         y = F.conv2d(x, sd[name + ".weight"], sd.get(name + ".bias"), stride=stride, padding=pad)

@@ -228,36 +228,48 @@ def resnet_images(n, seed):
 
 
 def g5_resnet50_hf():
+    """Graph wiring against code this build did not write: Hugging Face transformers' ResNetModel with the build's deterministic
+    weights.  Variant (stride_on_first_1x1, ceil_mode): (1, 1) is the published Caffe-style graph (keys pool5_f32 / pool5_f64);
+    (0, 1), (1, 0), (0, 0) pin the other settings of the two knobs SURVEY 8(c) keeps open (keys pool5_f64_v01 ...)."""
     import transformers
     from transformers import ResNetConfig, ResNetModel
     sd = weights.make_resnet50_state_dict(seed=0)
-    model = ResNetModel(ResNetConfig(downsample_in_bottleneck=True)).eval()
-    model.embedder.pooler = torch.nn.MaxPool2d(kernel_size=3, stride=2, padding=0, ceil_mode=True)   # pool1_3x3_s2 (Caffe)
-    hf = {}
 
-    def put(dst, src):
-        hf[dst + ".convolution.weight"] = torch.from_numpy(sd[src + ".weight"])
-        for k in ("weight", "bias", "running_mean", "running_var"):
-            hf[dst + ".normalization." + k] = torch.from_numpy(sd[src + "_bn." + k])
+    def build(stride_on_first_1x1, ceil_mode):
+        model = ResNetModel(ResNetConfig(downsample_in_bottleneck=bool(stride_on_first_1x1))).eval()
+        model.embedder.pooler = torch.nn.MaxPool2d(kernel_size=3, stride=2, padding=0, ceil_mode=bool(ceil_mode))   # pool1_3x3_s2
+        hf = {}
 
-    put("embedder.embedder", "conv1_7x7_s2")
-    for si, (stage, blocks, _, _, _) in enumerate(weights.RESNET50_STAGES):
-        for b in range(1, blocks + 1):
-            pre, dst = "conv%d_%d_" % (stage, b), "encoder.stages.%d.layers.%d" % (si, b - 1)
-            if b == 1:
-                put(dst + ".shortcut", pre + "1x1_proj")
-            put(dst + ".layer.0", pre + "1x1_reduce")
-            put(dst + ".layer.1", pre + "3x3")
-            put(dst + ".layer.2", pre + "1x1_increase")
-    missing, unexpected = model.load_state_dict(hf, strict=False)
-    assert not unexpected and all(k.endswith("num_batches_tracked") for k in missing), (missing, unexpected)
+        def put(dst, src):
+            hf[dst + ".convolution.weight"] = torch.from_numpy(sd[src + ".weight"])
+            for k in ("weight", "bias", "running_mean", "running_var"):
+                hf[dst + ".normalization." + k] = torch.from_numpy(sd[src + "_bn." + k])
+
+        put("embedder.embedder", "conv1_7x7_s2")
+        for si, (stage, blocks, _, _, _) in enumerate(weights.RESNET50_STAGES):
+            for b in range(1, blocks + 1):
+                pre, dst = "conv%d_%d_" % (stage, b), "encoder.stages.%d.layers.%d" % (si, b - 1)
+                if b == 1:
+                    put(dst + ".shortcut", pre + "1x1_proj")
+                put(dst + ".layer.0", pre + "1x1_reduce")
+                put(dst + ".layer.1", pre + "3x3")
+                put(dst + ".layer.2", pre + "1x1_increase")
+        missing, unexpected = model.load_state_dict(hf, strict=False)
+        assert not unexpected and all(k.endswith("num_batches_tracked") for k in missing), (missing, unexpected)
+        return model
+
     out = {"transformers_version": transformers.__version__, "weight_seed": 0}
-    for prec, dt in (("f32", torch.float32), ("f64", torch.float64)):
-        m = model.to(dt)
-        with torch.no_grad():
-            y = m(torch.from_numpy(resnet_images(2, 7)).to(dt)).pooler_output     # [2,2048,1,1] = AdaptiveAvgPool of stage 4
-        out["pool5_" + prec] = y.reshape(2, 2048).numpy()
-    print("G5", out["pool5_f32"].shape, np.abs(out["pool5_f32"]).max(), np.abs(out["pool5_f32"] - out["pool5_f64"]).max())
+    for (s1, cm), tag in (((1, 1), ""), ((0, 1), "_v01"), ((1, 0), "_v10"), ((0, 0), "_v00")):
+        model = build(s1, cm)
+        for prec, dt in (("f32", torch.float32), ("f64", torch.float64)):
+            if tag and prec == "f32":
+                continue
+            m = model.to(dt)
+            with torch.no_grad():
+                y = m(torch.from_numpy(resnet_images(2, 7)).to(dt)).pooler_output     # [2,2048,1,1] = AdaptiveAvgPool of stage 4
+            out["pool5_" + prec + tag] = y.reshape(2, 2048).numpy()
+    print("G5", out["pool5_f32"].shape, np.abs(out["pool5_f32"]).max(), np.abs(out["pool5_f32"] - out["pool5_f64"]).max(),
+          [float(np.abs(out["pool5_f64" + t] - out["pool5_f64"]).max()) for t in ("_v01", "_v10", "_v00")])
     np.savez_compressed(os.path.join(HERE, "resnet50_hf.npz"), **out)
 
 

@@ -115,7 +115,16 @@ def test_default_line_has_the_contract_fields():
     assert ph["floor_mfma_ms"] > ph["floor_hbm_ms"] > 0 and ph["limiting_floor"] == "mfma" and 0 < ph["frac_of_limiting_floor"] < 1
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["cpu_model"] and cb["deduplicated"]["value"] > 0
+    # round 5: what the CPU figure is made of (library versions, per-stage rates) and the "as tuned" variant beside the reference-faithful one
+    assert "MKL" in cb["torch_cpu_libraries"] or "OpenMP" in cb["torch_cpu_libraries"]
+    assert cb["stage_rates"]["resnet50_GFLOP_per_s_per_process"] > 0 and cb["as_tuned"]["value"] > 0
+    assert cb["as_tuned"]["stage_rates"]["resnet50_GFLOP_per_s_per_process"] > 0
     ex = d["extra"]
     assert ex["direct_form"]["value"] > 0 and ex["multi_snippet"]["gru_seq_len"] == 5 and ex["multi_snippet"]["value"] > 0
     assert ex["streamed"]["value"] > 0 and ex["streamed"]["pcie_GB_per_s"] > 0
+    # round 5: per-stage rates for BASELINE configs[1] / configs[2] in the driver-visible line
+    for k in ("clips_32", "clips_256"):
+        assert ex["phase_only"][k]["value"] > 1e5 and 0 < ex["phase_only"][k]["frac_of_hbm_peak"] < 1
+    for k in ("batch_64", "batch_256"):
+        assert ex["resnet50_only"][k]["value"] > 1e3 and 0 < ex["resnet50_only"][k]["frac_of_fp32_mfma_peak_algorithmic"] < 1.2
     assert d["parity_vs_cpu_sample"]["max_abs_err_valence_arousal"] < 1e-4

@@ -343,9 +343,64 @@ def test_profiles_hold_pmc_summaries_for_the_head_kernel_sources():
     assert len(lb["launches"]) > 90 and 0.5 < lb["mixed_frac"] < 1.0 and lb["step_floor_ms"] > 60
 
 
-def test_parse_partitions():
-    from mimamo_net_amd.stream import parse_partitions
-    assert parse_partitions("") is None
-    lanes = parse_partitions("0-127/128-255")
-    assert [len(l) for l in lanes] == [128, 128] and lanes[0][0] == 0 and lanes[1][-1] == 255
-    assert parse_partitions("0-3,8,10-11/5") == [[0, 1, 2, 3, 8, 10, 11], [5]]
+MODEL_DEF = """
+import torch
+import torch.nn as nn
+
+
+class Resnet50_ferplus_dag(nn.Module):
+
+    def __init__(self):
+        super(Resnet50_ferplus_dag, self).__init__()
+        self.meta = {'mean': [%(mean)s],
+                     'std': [1, 1, 1],
+                     'imageSize': [224, 224, 3]}
+        self.conv1_7x7_s2 = nn.Conv2d(3, 64, kernel_size=[7, 7], stride=(2, 2), padding=(3, 3), bias=False)
+        self.conv1_7x7_s2_bn = nn.BatchNorm2d(64, eps=%(eps)s, momentum=0.1, affine=True, track_running_stats=True)
+        self.conv1_relu_7x7_s2 = nn.ReLU()
+        self.pool1_3x3_s2 = nn.MaxPool2d(kernel_size=[3, 3], stride=[2, 2], padding=(0, 0), dilation=1, ceil_mode=%(ceil)s)
+        self.conv3_1_1x1_reduce = nn.Conv2d(256, 128, kernel_size=[1, 1], stride=(%(s1)d, %(s1)d), bias=False)
+        self.conv3_1_3x3 = nn.Conv2d(128, 128, kernel_size=[3, 3], stride=(%(s3)d, %(s3)d), padding=(1, 1), bias=False)
+        raise RuntimeError("a definition file is read, never executed")
+
+
+def resnet50_ferplus_dag(weights_path=None, **kwargs):
+    raise RuntimeError("a definition file is read, never executed")
+"""
+
+
+def test_model_definition_file_is_read_without_executing_it(tmp_path):
+    """`<benchmark_dir>/ferplus/<model_name>.py` is the file the reference executes (api/utils/model_utils.py:65-79) to get the graph and
+    `model.meta` (api/resnet50_extractor.py:38-41); the product reads the same facts with `ast`."""
+    p = tmp_path / "resnet50_ferplus_dag.py"
+    p.write_text(MODEL_DEF % dict(mean="131.0912, 103.8827, 91.4953", eps="1e-05", ceil="True", s1=2, s3=1))
+    d = weights.read_model_definition(str(p))
+    assert d == {"meta": {"mean": [131.0912, 103.8827, 91.4953], "std": [1, 1, 1], "imageSize": [224, 224, 3]},
+                 "stride_on_first_1x1": True, "ceil_mode": True, "bn_eps": 1e-5}
+    p.write_text(MODEL_DEF % dict(mean="91.5, 103.9, 131.1", eps="0.001", ceil="False", s1=1, s3=2))
+    d = weights.read_model_definition(str(p))
+    assert d["meta"]["mean"] == [91.5, 103.9, 131.1] and d["stride_on_first_1x1"] is False and d["ceil_mode"] is False
+    assert d["bn_eps"] == 1e-3
+    p.write_text("x = 1\n")
+    assert weights.read_model_definition(str(p)) == {}
+
+
+def test_conv_bias_is_folded_into_the_batchnorm_mean(oracle):
+    """A checkpoint with conv biases (the published definition has bias=False; a re-export may not): BN(conv + b) == BN' (conv) with
+    running_mean' = mean - b.  Checked on the blob and, through the oracle, on the first layer's output."""
+    sd = weights.make_resnet50_state_dict(seed=3)
+    plain = weights.resnet50_blob(sd)
+    biased = dict(sd)
+    for name, _, cout, _, _, _ in weights.resnet50_layers():
+        biased[name + ".bias"] = weights.det_uniform(name + ".bias", (cout,), -0.5, 0.5, 3)
+    blob = weights.resnet50_blob(biased)
+    assert blob.shape == plain.shape and not np.array_equal(blob, plain)
+    # first layer: conv weight 64*3*49, then gamma, beta, mean, var
+    off = 64 * 3 * 49
+    np.testing.assert_array_equal(blob[:off + 128], plain[:off + 128])
+    np.testing.assert_allclose(blob[off + 128:off + 192], sd["conv1_7x7_s2_bn.running_mean"] - biased["conv1_7x7_s2.bias"], rtol=0, atol=1e-7)
+    np.testing.assert_array_equal(blob[off + 192:off + 256], plain[off + 192:off + 256])
+    folded = dict(sd)
+    for name, _, _, _, _, _ in weights.resnet50_layers():
+        folded[name + "_bn.running_mean"] = (sd[name + "_bn.running_mean"].astype(np.float64) - biased[name + ".bias"]).astype(np.float32)
+    np.testing.assert_array_equal(weights.resnet50_blob(folded), blob)

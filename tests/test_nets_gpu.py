@@ -502,6 +502,90 @@ def test_checkpoints_in_the_third_party_layout_load_from_disk(oracle, dev, tmp_p
     assert res["v"].shape == (20, 2) and np.isfinite(res["v"].values).all()
 
 
+@pytest.mark.parametrize("variant", [(0, 0), (0, 1), (1, 0)])
+def test_resnet50_graph_variants_vs_oracle_and_third_party(oracle, golden, dev, variant):
+    """The parts of the third-party graph the reference's code does not pin: stride 2 on a stage's first 1x1 (1) or on
+    its 3x3 (0), pool1 with ceil_mode (1: 56 x 56) or floor (0: 55 x 55 maps with ragged Winograd tiles), through
+    Resnet50_Extractor(stride_on_first_1x1=, ceil_mode=): against the oracle with the same flags on fresh inputs and against the Hugging
+    Face ResNetModel run of tests/golden/make_golden.py g5 (downsample_in_bottleneck=False / MaxPool2d(ceil_mode=False))."""
+    from mimamo_net_amd.resnet50_extractor import Resnet50_Extractor
+    s1, cm = variant
+    sd = weights.make_resnet50_state_dict(seed=0)
+    ext = Resnet50_Extractor(state_dict=sd, device=dev, stride_on_first_1x1=bool(s1), ceil_mode=bool(cm))
+    assert (ext.stride_on_first_1x1, ext.ceil_mode, ext.bn_eps) == (bool(s1), bool(cm), 1e-5)
+    x = _images(3, 11)
+    want = oracle.resnet50_pool5(sd, x, stride_on_first_1x1=bool(s1), ceil_mode=bool(cm))
+    xt = torch.from_numpy(x).to(dev)
+    scale = np.abs(want).max()
+    try:
+        for mode in (True, 0):
+            ext.set_winograd(mode)
+            got = ext.get_vec(xt).cpu().numpy()
+            mx, mean = np.abs(got - want).max() / scale, np.abs(got - want).mean() / scale
+            print("variant %s winograd %s: max rel %.2e mean rel %.2e" % (variant, mode, mx, mean))
+            assert mx < POOL5_RTOL * 10 and mean < POOL5_RTOL, (variant, mode, mx, mean)
+            assert mx < POOL5_TIGHT_MAX and mean < POOL5_TIGHT_MEAN, ("regression bound", variant, mode, mx, mean)
+    finally:
+        ext.set_winograd(True)
+    g = golden("resnet50_hf")
+    xh = weights.det_uniform("resnet.img", (2, 3, 224, 224), 0.0, 1.0, 7)
+    xh = (xh * np.float32(255.0) - np.asarray(weights.RESNET50_MEAN, dtype=np.float32)[None, :, None, None]).astype(np.float32)
+    wh = g["pool5_f64_v%d%d" % (s1, cm)]
+    gh = ext.get_vec(torch.from_numpy(xh).to(dev)).cpu().numpy()
+    mx, mean = np.abs(gh - wh).max() / np.abs(wh).max(), np.abs(gh - wh).mean() / np.abs(wh).max()
+    print("variant %s vs HF ResNetModel: max rel %.2e mean rel %.2e" % (variant, mx, mean))
+    assert mx < POOL5_TIGHT_MAX and mean < POOL5_TIGHT_MEAN, (variant, mx, mean)
+    # and it is NOT the published graph's answer
+    assert np.abs(gh - g["pool5_f64"]).max() / np.abs(wh).max() > 1e-3
+    ext.close()
+
+
+def test_resnet50_bn_eps_conv_bias_and_definition_file(oracle, dev, tmp_path):
+    """(a) bn_eps other than 1e-5 (b) a checkpoint whose convs carry biases: folded into the BatchNorm shift (weights.resnet50_blob)
+    (c) a model definition file next to the weights settles stride placement / ceil_mode / eps / meta['mean'] the way the file the
+    reference executes would (api/utils/model_utils.py:65-79, api/resnet50_extractor.py:38-41); explicit keywords win."""
+    from mimamo_net_amd.resnet50_extractor import Resnet50_Extractor
+    from test_host_logic import MODEL_DEF
+    sd = weights.make_resnet50_state_dict(seed=5)
+    x = _images(2, 12)
+    xt = torch.from_numpy(x).to(dev)
+
+    def close_to(ext, want):
+        got = ext.get_vec(xt).cpu().numpy()
+        scale = np.abs(want).max()
+        mx, mean = np.abs(got - want).max() / scale, np.abs(got - want).mean() / scale
+        assert mx < POOL5_TIGHT_MAX and mean < POOL5_TIGHT_MEAN, (mx, mean)
+        return got
+    # (a)
+    ext = Resnet50_Extractor(state_dict=sd, device=dev, bn_eps=1e-3)
+    a = close_to(ext, oracle.resnet50_pool5(sd, x, eps=1e-3))
+    assert np.abs(a - oracle.resnet50_pool5(sd, x)).max() / np.abs(a).max() > 1e-5      # eps is visible in the result
+    ext.close()
+    # (b)
+    biased = dict(sd)
+    for name, _, cout, _, _, _ in weights.resnet50_layers():
+        biased[name + ".bias"] = weights.det_uniform(name + ".bias", (cout,), -0.3, 0.3, 5)
+    ext = Resnet50_Extractor(state_dict=biased, device=dev)
+    b = close_to(ext, oracle.resnet50_pool5(biased, x))
+    assert np.abs(b - oracle.resnet50_pool5(sd, x)).max() / np.abs(b).max() > 1e-3
+    ext.close()
+    # (c)
+    bdir = tmp_path / "pytorch-benchmarks"
+    os.makedirs(bdir / "ferplus")
+    torch.save({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, str(bdir / "ferplus" / "resnet50_ferplus_dag.pth"))
+    (bdir / "ferplus" / "resnet50_ferplus_dag.py").write_text(
+        MODEL_DEF % dict(mean="120.5, 100.25, 90.0", eps="0.001", ceil="False", s1=1, s3=2))
+    ext = Resnet50_Extractor(benchmark_dir=str(bdir))
+    assert (ext.stride_on_first_1x1, ext.ceil_mode, ext.bn_eps) == (False, False, 1e-3)
+    assert ext.meta == {"mean": [120.5, 100.25, 90.0], "std": [1, 1, 1], "imageSize": [224, 224, 3]}
+    close_to(ext, oracle.resnet50_pool5(sd, x, stride_on_first_1x1=False, ceil_mode=False, eps=1e-3))
+    ext.close()
+    ext = Resnet50_Extractor(benchmark_dir=str(bdir), stride_on_first_1x1=True, ceil_mode=True, bn_eps=1e-5, mean=weights.RESNET50_MEAN)
+    assert ext.meta["mean"] == list(weights.RESNET50_MEAN)
+    close_to(ext, oracle.resnet50_pool5(sd, x))
+    ext.close()
+
+
 WINO_STRESS = {
     # BN gamma of reduce/3x3 in [0.5, 4] (8x per-channel dynamic range into every 3x3 layer), weakly damped increase
     # layers: activations of 1e3 .. 1e4 inside the blocks, pool5 ~ 1e3

@@ -167,39 +167,6 @@ def test_lanes_on_several_streams_are_bit_identical(tester):
             assert torch.equal(a, b)
 
 
-def test_lanes_on_cu_partitioned_streams_are_bit_identical(tester):
-    """mm_stream_create_cu_mask through stream.PartitionStream / HotPath.set_lane_partitions (round-4 measurement lever): kernels
-    confined to CU subsets -- complementary halves, and an uneven overlapping pair -- compute the same bits as ordinary streams; the
-    mask read back from the runtime is the one asked for; a mask without any CU is refused."""
-    import ctypes
-    from mimamo_net_amd import _lib
-    from mimamo_net_amd.stream import PartitionStream
-    lengths = [64, 40, 64]
-    clips = [synthetic.make_clip_u8(80 + i, n) for i, n in enumerate(lengths)]
-    frames = torch.from_numpy(np.concatenate(clips)).to(tester.device)
-    plan = tester.hot.plan(lengths)
-    with torch.no_grad():
-        a = tester.hot.forward_u8(frames, plan)
-        try:
-            for parts in ([range(0, 128), range(128, 256)], [range(0, 192), range(64, 256)]):
-                tester.hot.set_lane_partitions(parts)
-                b = tester.hot.forward_lanes((frames,), lengths, 2, from_u8=True)
-                torch.cuda.synchronize()
-                assert torch.equal(a, b)
-        finally:
-            tester.hot.set_lane_partitions(None)
-        c = tester.hot.forward_lanes((frames,), lengths, 2, from_u8=True)
-        assert torch.equal(a, c)
-    ps = PartitionStream(range(0, 64))
-    back = (ctypes.c_uint32 * 8)()
-    assert _lib.lib().mm_stream_get_cu_mask(ps._h, back, 8) == 0
-    assert back[0] == 0xFFFFFFFF and back[1] == 0xFFFFFFFF and all(back[i] == 0 for i in range(2, 8))
-    ps.close()
-    zero = (ctypes.c_uint32 * 8)()
-    h = ctypes.c_void_p()
-    assert _lib.lib().mm_stream_create_cu_mask(ctypes.byref(h), zero, 8) == -1 and not h.value
-
-
 def test_bench_sized_step_is_deterministic(tester):
     """BASELINE configs[3] at bench size (32 clips x 64 frames, two lanes): chip-filling launches of every kernel on the
     path are bit-identical run to run and equal to the single-stream pass (load-dependent races show up here first)."""
