@@ -35,7 +35,10 @@ using namespace blur;
 //      whole windows of slowly moving faces)
 //   C  spatial means, clamp, store.  NHWC pixels take 48 of their 96 bytes from this band: the rows go through LDS so that three
 //      consecutive lanes write the 48 contiguous bytes of a pixel (a lane-per-pixel-strip store issues 64 separate 16-byte requests
-//      per instruction: 0.16 of the 0.61 ms these kernels took)
+//      per instruction: 0.16 of the 0.61 ms these kernels took).  A thread's four pixels are 12 float4 slots; its block in the staging
+//      is 13 slots long (round 5): with 12, eight consecutive lanes of a ds_write_b128 fall on two of the eight 16-byte bank groups
+//      (192-byte lane stride: 35 % of the kernel's LDS-active cycles were bank conflicts, PMC SQ_LDS_BANK_CONFLICT), with the odd
+//      stride on all eight
 // F = frames per barrier round (three barriers each).  A 9-wave workgroup at ~160 registers is alone on its CU, so the whole
 // 160 KB of LDS is its to use: F planes of blur input + row-pass output.
 template <int W, int F>
@@ -46,7 +49,11 @@ phase_window2_kernel(const float* __restrict__ fr, const int32_t* __restrict__ i
     constexpr int RPG = W == 48 ? 16 : 12;                    // rows per store group: RPG * W * 12 floats staged at a time
     constexpr int G = W / RPG;
     constexpr int WORK = F * (C::IN_PLANE + C::TMP_PLANE);
-    static_assert(RPG * W * (P - 1) <= WORK, "store staging fits the blur planes");
+#ifndef MM_PW_STAGE_PAD
+#define MM_PW_STAGE_PAD 1                                     // 0: the round-4 staging (12-slot thread blocks), for the A/B
+#endif
+    constexpr int SLOTS = 3 * PX + MM_PW_STAGE_PAD;           // float4 slots per thread block in the store staging: 12 used + 1 pad
+    static_assert(RPG * C::STRIPS * SLOTS * 4 <= WORK, "store staging fits the blur planes");
     extern __shared__ __attribute__((aligned(16))) float lds[];      // WORK + 64 * (P - 1) floats + first_wrap
     int& first_wrap = *reinterpret_cast<int*>(lds + WORK + 64 * (P - 1));
     float* in_x = lds;                              // [F][IN_PLANE]
@@ -183,10 +190,11 @@ phase_window2_kernel(const float* __restrict__ fr, const int32_t* __restrict__ i
         }
         return;
     }
-    float4* stage = reinterpret_cast<float4*>(lds);      // [RPG * W pixels][3 float4]
+    float4* stage = reinterpret_cast<float4*>(lds);      // [RPG * STRIPS thread blocks][SLOTS float4]: pixel-major, 3 float4 per pixel
 #pragma unroll
     for (int g = 0; g < G; ++g) {
         if (active && y / RPG == g) {
+            float4* mine = stage + (tid - g * RPG * C::STRIPS) * SLOTS;
 #pragma unroll
             for (int p = 0; p < PX; ++p)
 #pragma unroll
@@ -196,14 +204,14 @@ phase_window2_kernel(const float* __restrict__ fr, const int32_t* __restrict__ i
                     v.y = fminf(fmaxf(d[4 * q + 1][p] - mean[4 * q + 1], -LIM), LIM);
                     v.z = fminf(fmaxf(d[4 * q + 2][p] - mean[4 * q + 2], -LIM), LIM);
                     v.w = fminf(fmaxf(d[4 * q + 3][p] - mean[4 * q + 3], -LIM), LIM);
-                    stage[((y - g * RPG) * W + x0 + p) * 3 + q] = v;
+                    mine[p * 3 + q] = v;
                 }
         }
         __syncthreads();
         for (int idx = tid; idx < RPG * W * 3; idx += C::NTHREADS) {
             const int pix = idx / 3, part = idx - pix * 3;
             float* dst = out + ((j * W + g * RPG) * W + pix) * out_cstride + out_coffset + band * (P - 1) + part * 4;
-            *reinterpret_cast<float4*>(dst) = stage[idx];
+            *reinterpret_cast<float4*>(dst) = stage[idx + MM_PW_STAGE_PAD * (idx / (3 * PX))];      // skip the pad slot of every thread block
         }
         if (g + 1 < G) __syncthreads();
     }

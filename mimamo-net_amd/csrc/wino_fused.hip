@@ -47,7 +47,17 @@ struct WinoFusedParams {
     const float* bias2;  // [C2]
     const float* res;    // INC 1: residual, NHWC [B][H][W][C2].  INC 2: the block input x, NHWC [B][H][W][Cout] -- the second K source
     int C2;              // 256
+    int ablate;          // -DMM_MEASURE builds only (results wrong by construction): bit 0 = every workgroup reads the V rows of the first
+                         // 1 024 tiles (L2-resident: the kernel without its V traffic), bit 1 = residual rows from the first 4 096 pixels
 };
+
+#ifndef MM_INC3_PAIR
+#define MM_INC3_PAIR 0      // 1: the conv3_x fused kernel exchanges two output positions per barrier (A/B variant of round 5)
+#endif
+// dynamic LDS of the eight-wave INC 3 instantiation: the operand ring, or the epilogue's tenants when those are larger
+__host__ __device__ constexpr int inc3_lds_bytes(int ring_bytes) {
+    return MM_INC3_PAIR && ring_bytes < (128 * 128 + 4 * 8 * 512 + 512) * 4 ? (128 * 128 + 4 * 8 * 512 + 512) * 4 : ring_bytes;
+}
 
 __device__ constexpr float kAt[4][6] = {{1, 1, 1, 1, 1, 0}, {0, 1, -1, 2, -2, 0}, {0, 1, 1, 4, 4, 0}, {0, 1, -1, 8, -8, 1}};
 static constexpr float kAtHost[4][6] = {{1, 1, 1, 1, 1, 0}, {0, 1, -1, 2, -2, 0}, {0, 1, 1, 4, 4, 0}, {0, 1, -1, 8, -8, 1}};
@@ -79,6 +89,11 @@ wino_fused_kernel(const WinoFusedParams p) {
     const int logical = xcd_contiguous(blockIdx.x, gridDim.x);
     const int tile_m = logical / p.tiles_n, tile_n = logical - tile_m * p.tiles_n;
     const int m_base = tile_m * BM, n_base = tile_n * BN;
+#ifdef MM_MEASURE
+    const int m_load = (p.ablate & 1) ? (m_base & 1023) : m_base;     // cost-sheet ablation: V rows from an L2-resident subset
+#else
+    const int m_load = m_base;
+#endif
     static_assert(BM % (4 * NW) == 0 && BN % (4 * NW) == 0, "whole 1 KB pieces per wave");
     const int K = p.K, kslabs = K / KS;
 
@@ -87,7 +102,7 @@ wino_fused_kernel(const WinoFusedParams p) {
 #pragma unroll
     for (int it = 0; it < NIA; ++it) {
         const int row = (it * NW + wave) * 4 + (lane >> 4);
-        va[it] = (unsigned)((m_base + row) * K + (((lane & 15) ^ (row & 15)) << 2)) * 4u;
+        va[it] = (unsigned)((m_load + row) * K + (((lane & 15) ^ (row & 15)) << 2)) * 4u;
     }
 #pragma unroll
     for (int it = 0; it < NIB; ++it) {
@@ -308,10 +323,11 @@ wino_fused_kernel(const WinoFusedParams p) {
         static_assert(WGM == 2 && WGN == 4 && NBUF == 3, "INC 3 is built for the 2 x 4 wave workgroup");
         constexpr int K2 = 128, ROWS2 = 128;
         constexpr int W2_FLOATS = ROWS2 * K2;                          // 64 KB
-        constexpr int XB_FLOATS = NW * 512;                            // one exchange buffer: 8 waves x 2 KB
-        static_assert((W2_FLOATS + 2 * XB_FLOATS + 512) * 4 <= NBUF * ROWS * KS * 4, "epilogue tenants fit the dead ring");
+        constexpr int XB_FLOATS = NW * 512;                            // one position's exchange area: 8 waves x 2 KB
+        constexpr int XPOS = MM_INC3_PAIR ? 2 : 1;                     // positions exchanged per barrier
+        static_assert((W2_FLOATS + 2 * XPOS * XB_FLOATS + 512) * 4 <= inc3_lds_bytes(NBUF * ROWS * KS * 4), "epilogue tenants fit");
         float* xb = lds + W2_FLOATS;
-        float* b2s = xb + 2 * XB_FLOATS;
+        float* b2s = xb + 2 * XPOS * XB_FLOATS;
         // (The exchange only couples the four waves of one tile half (same wm).  A per-half barrier on an LDS counter -- ds_add to
         //  arrive, poll to wait -- instead of the workgroup-wide s_barrier below was built and measured: 103.64-103.84 vs
         //  103.30-103.66 ms per step on one box, profiles/r04_ab_inc3_barrier.txt: the polling costs what the decoupling gains.)
@@ -378,6 +394,64 @@ wino_fused_kernel(const WinoFusedParams p) {
             f32x4v rs[2][2], Pr[3][2];
             res_rows(rs[0], 0);
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");   // the matrix quarter (and position 0's residual rows) landed
+#if MM_INC3_PAIR
+            // Two positions per exchange round (round 5): the eight waves of the workgroup meet at 8 instead of 16 barriers per pass,
+            // 128 MFMAs per wave between them; the exchange area holds 2 x 2 positions (32 KB more than the dead ring: 130 KB)
+            f32x4v Pq[2][3][2];
+#pragma unroll
+            for (int pr = 0; pr < 8; ++pr) {
+                float* xbuf = xb + (pr & 1) * 2 * XB_FLOATS;
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+#pragma unroll
+                    for (int cb = 0; cb < 2; ++cb)
+                        *reinterpret_cast<f32x4v*>(xbuf + h * XB_FLOATS + x_own + cb * 256) = Y[(2 * pr + h) >> 2][(2 * pr + h) & 3][cb];
+                // buffer (pr & 1) was last read in round pr - 2; every wave has passed the barrier of round pr - 1, i.e. finished those reads
+                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+#pragma unroll
+                    for (int k = 0; k < 3; ++k)
+#pragma unroll
+                        for (int cb = 0; cb < 2; ++cb) Pq[h][k][cb] = *reinterpret_cast<const f32x4v*>(xbuf + h * XB_FLOATS + xr[k] + cb * 256);
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int pos = 2 * pr + h, pp = pos >> 2, qq = pos & 3;
+                    if (pos + 1 < 16) res_rows(rs[(pos + 1) & 1], pos + 1);
+                    f32x4v acc[2];
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) acc[j] = *reinterpret_cast<const f32x4v*>(b2s + c0 + j * 16);
+#pragma unroll
+                    for (int sidx = 0; sidx < 8; ++sidx) {
+                        const f32x4v Bv = sidx < 2 ? Y[pp][qq][sidx & 1] : Pq[h][(sidx - 2) >> 1][sidx & 1];
+                        float4 w4[2];
+#pragma unroll
+                        for (int j = 0; j < 2; ++j) w4[j] = *reinterpret_cast<const float4*>(lds + wa[sidx] + (j * 16) * K2);
+#pragma unroll
+                        for (int j = 0; j < 2; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(w4[j].x, Bv[0], acc[j], 0, 0, 0);
+#pragma unroll
+                        for (int j = 0; j < 2; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(w4[j].y, Bv[1], acc[j], 0, 0, 0);
+#pragma unroll
+                        for (int j = 0; j < 2; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(w4[j].z, Bv[2], acc[j], 0, 0, 0);
+#pragma unroll
+                        for (int j = 0; j < 2; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(w4[j].w, Bv[3], acc[j], 0, 0, 0);
+                    }
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        acc[j] = acc[j] + rs[pos & 1][j];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) acc[j][e] = fmaxf(acc[j][e], 0.f);
+                    }
+                    if (tok && 4 * ty + pp < p.H && 4 * tx + qq < p.W) {
+                        float* op = obase + ((int64_t)pp * p.W + qq) * p.C2;
+#pragma unroll
+                        for (int j = 0; j < 2; ++j) __builtin_nontemporal_store(acc[j], reinterpret_cast<f32x4v*>(op + j * 16));
+                    }
+                }
+            }
+            (void)Pr;
+            continue;
+#endif
 #pragma unroll
             for (int pos = 0; pos < 16; ++pos) {
                 const int pp = pos >> 2, qq = pos & 3;
@@ -593,7 +667,13 @@ wino_fused_kernel(const WinoFusedParams p) {
         auto res_rows = [&](f32x4v (&r)[4], int step) {
             const int pp = step >> 3, qq = (step >> 1) & 3, h = step & 1;
             const bool pok = tok && 4 * ty + pp < p.H && 4 * tx + qq < p.W;
+#ifdef MM_MEASURE
+            const float* rp = !pok ? p.res + c0
+                              : (p.ablate & 2) ? p.res + ((pix0 + (int64_t)pp * p.W + qq) & 4095) * p.C2 + c0
+                                               : rbase + ((int64_t)pp * p.W + qq) * p.C2;
+#else
             const float* rp = pok ? rbase + ((int64_t)pp * p.W + qq) * p.C2 : p.res + c0;   // clipped pixel: a valid address, nothing stored
+#endif
 #pragma unroll
             for (int j = 0; j < 4; ++j) r[j] = *reinterpret_cast<const f32x4v*>(rp + h * 64 + j * 16);
         };
@@ -705,7 +785,8 @@ static int launch_fused(WinoFusedParams p, hipStream_t s) {
     constexpr int BM = 16 * WGM, BN = 32 * WGN;
     // INC: the increase matrix (64 KB) + exchange area (8 KB) take the dead operand ring, bias2 (1 KB) sits behind it: 73 KB, two
     // workgroups per CU still fit the 160 KB
-    constexpr int LDS_BYTES = (INC == 1 || INC == 2) ? (256 * 64 + 2048 + 256) * 4 : NBUF * (BM + BN) * 64 * 4;
+    constexpr int LDS_BYTES = (INC == 1 || INC == 2) ? (256 * 64 + 2048 + 256) * 4
+                              : INC == 3 ? inc3_lds_bytes(NBUF * (BM + BN) * 64 * 4) : NBUF * (BM + BN) * 64 * 4;
     static_assert(LDS_BYTES >= NBUF * (BM + BN) * 64 * 4, "the ring must fit too");
     static bool attr_set[16] = {};
     int dev = 0;
@@ -715,6 +796,20 @@ static int launch_fused(WinoFusedParams p, hipStream_t s) {
                                    LDS_BYTES));
         attr_set[dev] = true;
     }
+#ifdef MM_MEASURE
+    // cost-side measurements (tools/ scripts, never the shipped library): MM_WF_LDS_PAD = extra dynamic LDS bytes (forces one workgroup
+    // per CU), MM_WF_ABLATE = see WinoFusedParams::ablate; both apply to the INC instantiations only
+    static const int lds_pad = getenv("MM_WF_LDS_PAD") ? atoi(getenv("MM_WF_LDS_PAD")) : 0;
+    static const int ablate = getenv("MM_WF_ABLATE") ? atoi(getenv("MM_WF_ABLATE")) : 0;
+    const int lds_bytes = LDS_BYTES + (INC ? lds_pad : 0);
+    p.ablate = INC ? ablate : 0;
+    if (INC && lds_pad)
+        MM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(wino_fused_kernel<NBUF, WGM, INC, WGN>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   lds_bytes));
+#else
+    constexpr int lds_bytes = LDS_BYTES;
+    p.ablate = 0;
+#endif
     p.tiles_n = (p.Cout + BN - 1) / BN;
     for (int q = 0; q < 6; ++q)
         for (int qq = 0; qq < 4; ++qq) p.at_cols[q * 4 + qq] = kAtHost[qq][q];
@@ -728,7 +823,7 @@ static int launch_fused(WinoFusedParams p, hipStream_t s) {
         if (INC) fl += 2.0 * (double)p.B * p.H * p.W * (double)(INC == 2 ? 2 * p.Cout : p.Cout) * (double)p.C2;
         prof_before(0, fl, s, tag);
     }
-    hipLaunchKernelGGL((wino_fused_kernel<NBUF, WGM, INC, WGN>), dim3((unsigned)blocks), dim3(WGM * WGN * 64), LDS_BYTES, s, p);
+    hipLaunchKernelGGL((wino_fused_kernel<NBUF, WGM, INC, WGN>), dim3((unsigned)blocks), dim3(WGM * WGN * 64), lds_bytes, s, p);
     prof_after(0, s);
     MM_LAUNCH_CHECK();
     return MM_OK;
