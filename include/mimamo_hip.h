@@ -100,13 +100,20 @@ int mm_phase_extract(mm_pyramid_t* h, const float* coeff, const int32_t* ids,
 
 /* extract() for ANY configuration (other band counts, plane sizes, window lengths than api/tester.py's):
  * coeff device f32 [planes, P, R, C, 2] (planes = batch*nbands, the reference's view at :97-98) ->
- * out [planes, P-1, R, C].  Same arithmetic as mm_phase_extract, generic and slower; R*C <= 4096, P >= 2,
- * otherwise MM_ERR_UNSUPPORTED.  Needs no handle (the Gaussian taps are compile-time constants).
+ * out [planes, P-1, R, C].  Same arithmetic as mm_phase_extract, generic and slower; R*C <= 4096 (larger planes: the _ws
+ * variant below), P >= 2, otherwise MM_ERR_UNSUPPORTED.  Needs no handle (the Gaussian taps are compile-time constants).
  * denoised (optional, may be NULL): [planes, P, R, C], the amplitude-blurred unwrapped phase with its spatial
  * mean removed -- what the training-side `Steerable_Pyramid_Phase.extract_phase(return_phase=True)` returns
  * (Aff-wild-exps/utils.py:367-418). */
 int mm_phase_extract_generic(const float* coeff, int64_t planes, int P, int R, int C, float* out, float* denoised,
                              void* stream);
+/* The same for planes of ANY size (the reference's extract takes any W x H, api/phase_difference_extractor.py:93): the blur planes and
+ * the per-pixel scan state live in a caller-owned workspace of mm_phase_extract_generic_workspace_bytes() bytes (0 = the plane fits the
+ * LDS kernel above and no workspace is needed; 8 floats per pixel and plane set otherwise).  A non-NULL workspace of sufficient size
+ * selects the workspace kernel whatever the plane size (bit-identical results where both apply); NULL / 0 bytes = mm_phase_extract_generic. */
+int64_t mm_phase_extract_generic_workspace_bytes(int64_t planes, int P, int R, int C);
+int mm_phase_extract_generic_ws(const float* coeff, int64_t planes, int P, int R, int C, float* out, float* denoised,
+                                void* workspace, int64_t workspace_bytes, void* stream);
 
 /* Fused, de-duplicated driver for one batch of frames (the build's fast path): ONE kernel per unique frame (pyramid,
  * atan2 / magnitude, the frame-only blurs; csrc/pyramid_frames.hip), then J windows gathered through window ids
@@ -132,8 +139,9 @@ int mm_phase_diff_planes(mm_pyramid_t* h, const float* planes, int64_t n, const 
  * General complex steerable pyramid -- replaces `SCFpyr_PyTorch(height, nbands, scale_factor,
  * device, precision).build(im_batch)` (api/steerable/SCFpyr_PyTorch.py:51-125 and
  * _build_levels :127-208) with its FULL return list: hi-pass residual, every oriented band of every
- * level, low-pass residual.  Arbitrary (non-mirrored) square images, even side <= 256 whose level
- * grids stay even (each 2-D transform's intermediate lives in LDS up to side 96, in the workspace above), height >= 2, 2 <= nbands <= 16; otherwise MM_ERR_UNSUPPORTED;
+ * level, low-pass residual.  Arbitrary (non-mirrored) square images of side <= 1024, even or odd, odd level grids included (each
+ * 2-D transform's intermediate lives in LDS up to side 96, in the workspace above; the transforms are DFTs by summation, O(side^3) per
+ * image: completeness, not speed), height >= 2, 2 <= nbands <= 16; otherwise MM_ERR_UNSUPPORTED;
  * `height > floor(log2(size)) - 2` returns MM_ERR_TOO_SMALL (the reference's RuntimeError, :90-91).
  * The inference hot path does not go through here (mm_pyramid_* exploits the mirrored input).
  * ------------------------------------------------------------------------------------- */
@@ -216,8 +224,10 @@ int64_t mm_head_blob_floats_mlp(int n_units, const int* units);
 int mm_head_create_mlp(mm_head_t** out, const float* host_blob, int64_t n_floats, int n_units, const int* units);
 /* Two_Stream_RNN(mlp_hidden_units, num_phase=...) (api/mimamo_net.py:97-112): PhaseNet takes 2 * num_phase channels per level
  * (phase_0 [bs,T,2*num_phase,48,48], phase_1 [bs,T,2*num_phase,24,24]); the state_dict's conv_net.0.0 / conv_net.1.0 weights have
- * 2*num_phase / 64 + 2*num_phase input channels.  num_phase must be even and <= 32 (16-byte channel groups), otherwise
- * MM_ERR_UNSUPPORTED (from both functions).  mm_head_create_mlp == num_phase 12 (api/tester.py:28). */
+ * 2*num_phase / 64 + 2*num_phase input channels.  Any num_phase in [1, 128] (MM_ERR_UNSUPPORTED beyond, from both functions).  An odd
+ * num_phase (2*num_phase not a multiple of the 16-byte channel group) runs on internally zero-padded channels and takes NCHW phase
+ * inputs only (mm_head_forward's phase_nhwc == 0; the channels-last entry points answer MM_ERR_UNSUPPORTED).
+ * mm_head_create_mlp == num_phase 12 (api/tester.py:28). */
 int64_t mm_head_blob_floats_cfg(int n_units, const int* units, int num_phase);
 int mm_head_create_cfg(mm_head_t** out, const float* host_blob, int64_t n_floats, int n_units, const int* units, int num_phase);
 int mm_head_destroy(mm_head_t* h);

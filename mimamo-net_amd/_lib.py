@@ -29,6 +29,8 @@ SIGNATURES = {
     "mm_pyramid_build_batch": (_i, [_vp, _vp, _i64, _i64, _vp, _vp, _vp]),
     "mm_phase_extract": (_i, [_vp, _vp, _vp, _i64, _i64, _i64, _i, _i, _vp, _i, _i, _i, _vp]),
     "mm_phase_extract_generic": (_i, [_vp, _i64, _i, _i, _i, _vp, _vp, _vp]),
+    "mm_phase_extract_generic_workspace_bytes": (_i64, [_i64, _i, _i, _i]),
+    "mm_phase_extract_generic_ws": (_i, [_vp, _i64, _i, _i, _i, _vp, _vp, _vp, _i64, _vp]),
     "mm_phase_workspace_bytes": (_i64, [_vp, _i64]),
     "mm_phase_diff_frames": (_i, [_vp, _vp, _i64, _vp, _i64, _vp, _i, _i, _i, _vp, _i, _i, _i, _vp, _i64, _vp]),
     "mm_phase_diff_planes": (_i, [_vp, _vp, _i64, _vp, _i64, _i, _vp, _i, _i, _i, _vp]),

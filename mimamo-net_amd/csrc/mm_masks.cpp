@@ -181,7 +181,7 @@ int build_scf_full_tables(int n0, int height, int nbands, int scale_factor, std:
         const double norm = 1.0 / ((double)n * n);
         for (int a = 0; a < n; ++a)
             for (int b = 0; b < n; ++b) {
-                const int u = (a + n / 2) % n, v = (b + n / 2) % n;  // fftshift of an even-sized grid
+                const int u = (a + n / 2) % n, v = (b + n / 2) % n;  // fftshift (either parity: the DC sample lands on n / 2)
                 const double m = mk[(size_t)u * n + v] * norm;
                 o.table[((size_t)a * n + b) * 2] = m * re;
                 o.table[((size_t)a * n + b) * 2 + 1] = m * im;
@@ -209,7 +209,11 @@ int build_scf_full_tables(int n0, int height, int nbands, int scale_factor, std:
         int s, e;
         crop_bounds(n, s, e);
         const int m = e - s;
-        if (m <= 0 || (m & 1)) return MM_ERR_UNSUPPORTED;  // odd grids shift differently; not produced by supported sizes
+        if (m <= 0) return MM_ERR_UNSUPPORTED;
+        // (odd grids: batch_fftshift2d rolls by n//2 + 1 and batch_ifftshift2d by n//2, math_utils.py:33-47, i.e. the standard
+        //  shifts -- FFT index a sits at shifted index (a + n/2) % n for either parity, which is what `emit` uses; the crop keeps
+        //  the DC sample at m/2: s + m/2 == n/2 for the reference's bounds)
+        if (s + m / 2 != n / 2) return MM_ERR_UNSUPPORTED;
         Grid g2;
         g2.n = m;
         g2.log_rad.resize((size_t)m * m);

@@ -306,6 +306,7 @@ struct mm_head {
     float* bhh[2][2];
     int winograd;   // 1 (default): PhaseNet's 128 -> 256 3x3 layer through the fused F(4x4,3x3) kernel; MM_HEAD_WINOGRAD=0: direct form
     int pc;         // PhaseNet input channels = 2 * num_phase (api/mimamo_net.py:112): 24 for the published model
+    int pcp;        // pc rounded up to a multiple of 4: channel stride of the NHWC phase buffers (== pc unless num_phase is odd)
     int device;
 };
 
@@ -340,7 +341,11 @@ static bool mlp_units_ok(int n_units, const int* units) {
     return true;
 }
 
-static bool phase_channels_ok(int pc) { return pc >= 4 && pc <= 64 && pc % 4 == 0; }   // 16-byte channel groups; 64 + pc <= 128 (Winograd K)
+// PhaseNet input channels pc = 2 * num_phase (api/mimamo_net.py:112): any num_phase up to 128.  Channel groups are 16 bytes, so an odd
+// num_phase (pc % 4 == 2) runs on buffers padded to pcp = pc rounded up to 4 with zero channels meeting zero weights; the concat layer takes
+// the fused Winograd kernel while 64 + pcp <= 128 and pc % 4 == 0, the direct form otherwise.
+static bool phase_channels_ok(int pc) { return pc >= 2 && pc <= 256 && pc % 2 == 0; }
+static int pad4(int c) { return (c + 3) / 4 * 4; }
 
 static int64_t head_blob_floats(int n_units, const int* units, int pc = 24) {
     int64_t n = 0;
@@ -627,7 +632,7 @@ int mm_head_create_mlp(mm_head_t** out, const float* blob, int64_t n_floats, int
 
 int64_t mm_head_blob_floats_cfg(int n_units, const int* units, int num_phase) {
     if (!mm::mlp_units_ok(n_units, units) || num_phase < 1) return (int64_t)MM_ERR_INVALID_ARG;
-    if (!mm::phase_channels_ok(2 * num_phase)) return (int64_t)MM_ERR_UNSUPPORTED;   // as mm_head_create_cfg: odd or > 32 differences
+    if (!mm::phase_channels_ok(2 * num_phase)) return (int64_t)MM_ERR_UNSUPPORTED;   // as mm_head_create_cfg: more than 128 differences
     return mm::head_blob_floats(n_units, units, 2 * num_phase);
 }
 
@@ -638,7 +643,7 @@ int mm_head_create_cfg(mm_head_t** out, const float* blob, int64_t n_floats, int
     const int pc = 2 * num_phase;
     if (!mlp_units_ok(n_units, units)) return MM_ERR_INVALID_ARG;
     if (num_phase < 1) return MM_ERR_INVALID_ARG;
-    if (!phase_channels_ok(pc)) return MM_ERR_UNSUPPORTED;      // odd num_phase (channel groups of 4) or more than 32 differences
+    if (!phase_channels_ok(pc)) return MM_ERR_UNSUPPORTED;      // more than 128 differences
     if (!blob || n_floats != head_blob_floats(n_units, units, pc)) return MM_ERR_INVALID_ARG;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return MM_ERR_NO_DEVICE;
@@ -646,6 +651,7 @@ int mm_head_create_cfg(mm_head_t** out, const float* blob, int64_t n_floats, int
     if (!h) return MM_ERR_INVALID_ARG;
     h->device = current_device_or(0);
     h->pc = pc;
+    h->pcp = pad4(pc);
     const float eps = 1e-5f;
     const float* p = blob;
     int rc = MM_OK;
@@ -660,9 +666,10 @@ int mm_head_create_cfg(mm_head_t** out, const float* blob, int64_t n_floats, int
     auto conv_bn_relu = [&](Layer& L, int o, int i, int stride, bool wino) {
         const float* w = take((int64_t)o * i * 9); const float* b = take(o); BN bn = take_bn(o);
         // Winograd-domain weights for the fused F(4x4,3x3) kernel (stride 1, K a multiple of 64) only for the two layers
-        // mm_head_forward runs through it: (64 + pc) -> 128 at 24x24 (the concat layer gets zero columns up to 128) and 128 -> 256
-        // at 12x12
-        if (rc == MM_OK) rc = make_layer(h->arena, L, w, b, o, i, 3, stride, 1, 1, &bn, nullptr, eps, wino, false, 64);
+        // mm_head_forward runs through it: (64 + pc) -> 128 at 24x24 (the concat layer gets zero columns up to 128; only while
+        // 64 + pc <= 128 and pc % 4 == 0 -- make_layer leaves wino_u4 null otherwise and the layer runs in the direct form) and
+        // 128 -> 256 at 12x12
+        if (rc == MM_OK) rc = make_layer(h->arena, L, w, b, o, i, 3, stride, 1, 1, &bn, nullptr, eps, wino && i <= 128, false, 64);
     };
     // Linear -> ReLU -> BN  (PhaseNet.fc :54-62, transform :115-117)
     auto lin_relu_bn = [&](Layer& L, int o, int i) {
@@ -728,7 +735,7 @@ namespace {
 struct HeadWs {
     int64_t p0n, a0, cat, a1, a2, a3, a4, pool, fc1, m1, feat, f, gi, gh, l0, l1, wv;
 };
-HeadWs head_sizes(int64_t N, int64_t T, int64_t mlp_max, bool wino, int pc) {
+HeadWs head_sizes(int64_t N, int64_t T, int64_t mlp_max, bool wino, int pc) {   // pc: the PADDED channel count (mm_head::pcp)
     HeadWs s;
     s.p0n = N * 48 * 48 * pc; s.a0 = N * 48 * 48 * 64; s.cat = N * 24 * 24 * (64 + pc); s.a1 = N * 24 * 24 * 128;
     s.a2 = N * 12 * 12 * 128; s.a3 = N * 12 * 12 * 256; s.a4 = N * 6 * 6 * 256; s.pool = N * 256; s.fc1 = N * 256;
@@ -742,7 +749,7 @@ HeadWs head_sizes(int64_t N, int64_t T, int64_t mlp_max, bool wino, int pc) {
 int64_t mm_head_workspace_bytes(mm_head_t* h, int64_t bs, int64_t T) {
     using mm::Bump;
     if (!h || bs < 0 || T < 0) return MM_ERR_INVALID_ARG;
-    const HeadWs s = head_sizes(bs * T, T, h->mlp_max, h->winograd != 0, h->pc);
+    const HeadWs s = head_sizes(bs * T, T, h->mlp_max, h->winograd != 0, h->pcp);
     const int64_t all[] = {s.p0n, s.a0, s.cat, s.a1, s.a2, s.a3, s.a4, s.pool, s.fc1, s.m1, s.feat, s.f, s.gi, s.gh, s.l0, s.l1, s.wv};
     int64_t tot = 0;
     for (int64_t v : all) tot += Bump::size_of(v);
@@ -760,7 +767,7 @@ int mm_head_forward(mm_head_t* h, const float* phase_0, const float* phase_1, in
     MM_CHECK_DEVICE(h);
     hipStream_t s = (hipStream_t)stream_;
     const int N = (int)N64;
-    const HeadWs z = head_sizes(N64, T, h->mlp_max, h->winograd != 0, h->pc);
+    const HeadWs z = head_sizes(N64, T, h->mlp_max, h->winograd != 0, h->pcp);
     Bump ws(workspace, workspace_bytes);
     float* p0n = ws.take(z.p0n); float* a0 = ws.take(z.a0); float* cat = ws.take(z.cat); float* a1 = ws.take(z.a1);
     float* a2 = ws.take(z.a2); float* a3 = ws.take(z.a3); float* a4 = ws.take(z.a4); float* pool = ws.take(z.pool);
@@ -771,10 +778,12 @@ int mm_head_forward(mm_head_t* h, const float* phase_0, const float* phase_1, in
 #define MM_TRY(x) do { rc = (x); if (rc != MM_OK) return rc; } while (0)
     // ---- temporal stream: PhaseNet (mimamo_net.py:79-92)
     const float* x0 = phase_0;
-    const int pc = h->pc, catc = 64 + pc;      // 24 / 88 for the published num_phase = 12
+    const int pc = h->pc, pcp = h->pcp, catc = 64 + pcp;      // 24 / 24 / 88 for the published num_phase = 12
+    if (phase_nhwc && pcp != pc) return MM_ERR_UNSUPPORTED;   // odd num_phase: channels-last inputs would need 16-byte channel groups; NCHW only
     if (!phase_nhwc) {
-        MM_TRY(nchw_to_nhwc(phase_0, p0n, N64, pc, 48 * 48, pc, 0, pc, s));
-        MM_TRY(nchw_to_nhwc(phase_1, cat, N64, pc, 24 * 24, catc, 64, pc, s));  // torch.cat([conv1, level1], dim=1) (:85)
+        // (channels [pc, pcp) of both buffers are zero-filled; their weights are zero columns)
+        MM_TRY(nchw_to_nhwc(phase_0, p0n, N64, pc, 48 * 48, pcp, 0, pcp, s));
+        MM_TRY(nchw_to_nhwc(phase_1, cat, N64, pc, 24 * 24, catc, 64, pcp, s));  // torch.cat([conv1, level1], dim=1) (:85)
         x0 = p0n;
     } else if (phase_nhwc == 2) {
         // phase_1 IS the concat buffer [N,24,24,64+pc] with the level-1 channels already at 64.. (written
@@ -785,7 +794,7 @@ int mm_head_forward(mm_head_t* h, const float* phase_0, const float* phase_1, in
         MM_HIP(hipMemcpy2DAsync(cat + 64, catc * sizeof(float), phase_1, pc * sizeof(float), pc * sizeof(float),
                                 (size_t)N64 * 24 * 24, hipMemcpyDeviceToDevice, s));
     }
-    MM_TRY(run_layer(h->conv[0], x0, N, 48, 48, pc, 0, a0, 64, 0, nullptr, 0, s));
+    MM_TRY(run_layer(h->conv[0], x0, N, 48, 48, pcp, 0, a0, 64, 0, nullptr, 0, s));
     MM_TRY(run_layer(h->conv[1], a0, N, 48, 48, 64, 0, cat, catc, 0, nullptr, 0, s));
     // the fused Winograd kernel declines (MM_ERR_UNSUPPORTED) what its 32-bit plane offsets cannot address: direct form then
     rc = MM_ERR_UNSUPPORTED;

@@ -1,7 +1,7 @@
 // General complex steerable pyramid: the whole return list of SCFpyr_PyTorch.build
 // (api/steerable/SCFpyr_PyTorch.py:70-208) -- hi-pass residual, every oriented band of every level, low-pass
-// residual -- for arbitrary (non-mirrored) square images up to 256x256 (the intermediate of each 2-D transform lives in
-// LDS up to 96x96, in a global scratch above), any height / number of bands, fp32 or fp64 I/O.
+// residual -- for arbitrary (non-mirrored) square images up to 1024x1024, even or odd (the intermediate of each 2-D transform lives
+// in LDS up to 96x96, in a global scratch above), any height / number of bands, fp32 or fp64 I/O.
 //
 // This is the API-completeness path, not the hot path: the inference pipeline uses pyramid.hip, which exploits the
 // mirror symmetry of its input and keeps only the coefficients the phase stage consumes.  Here every transform is a
@@ -14,6 +14,7 @@
 //             (image, output o); T_o = the reference's mask product for that output on its (cropped) grid, in FFT
 //             order, with 1/m^2 and the (-i)^(nbands-1) band factor folded in (mm_masks.cpp); a' = a's signed
 //             frequency taken modulo n0 (the reference's centre crops of the shifted spectrum keep signed frequency).
+#include <algorithm>
 #include <cmath>
 #include <new>
 #include "mm_common.h"
@@ -24,6 +25,8 @@ struct mm_scfpyr {
     int n_out;
     std::vector<int> side, is_complex;
     std::vector<double2*> d_table;  // per output, device
+    std::vector<double2*> d_tw;     // per output: e^{+2 pi i k / side}, [side] (outputs of one side share the table)
+    std::vector<double2*> d_tw_own; // the distinct twiddle allocations
     double2* d_twiddle;             // [size]  e^{+2 pi i k / size}
 };
 
@@ -32,7 +35,7 @@ namespace {
 
 constexpr int kScfThreads = 256;
 constexpr int kScfLdsSide = 96;   // LDS-resident intermediate: side^2 complex float64 = 147 456 B at 96
-constexpr int kScfMaxSide = 256;  // above kScfLdsSide the intermediate goes through a global scratch (L2-resident)
+constexpr int kScfMaxSide = 1024; // above kScfLdsSide the intermediate goes through a global scratch; O(side^3) per image: completeness, not speed
 
 template <typename TIn>
 __global__ __launch_bounds__(kScfThreads) void scf_forward_kernel(const TIn* __restrict__ im, double2* __restrict__ F,
@@ -81,13 +84,12 @@ __global__ __launch_bounds__(kScfThreads) void scf_inverse_kernel(const double2*
                                                                   const double2* __restrict__ tw, TOut* __restrict__ out,
                                                                   int n0, int m, int is_complex, double2* scratch) {
     extern __shared__ __attribute__((aligned(16))) double2 sm[];
-    double2* w = sm;                                                                 // [m]   e^{+2 pi i k/m} = tw[k * n0/m]
+    double2* w = sm;                                                                 // [m]   e^{+2 pi i k/m}: this level's own table
     double2* Y = scratch ? scratch + (size_t)blockIdx.x * m * m : sm + m;           // [m][m]
-    const int step = n0 / m;
-    for (int k = threadIdx.x; k < m; k += kScfThreads) w[k] = tw[k * step];
+    for (int k = threadIdx.x; k < m; k += kScfThreads) w[k] = tw[k];
     __syncthreads();
     const double2* Fi = F + (size_t)blockIdx.x * n0 * n0;
-    const int h = m / 2;
+    const int h = (m + 1) / 2;             // FFT indices [0, h) are the non-negative frequencies (odd m: one more than the negative ones)
     for (int idx = threadIdx.x; idx < m * m; idx += kScfThreads) {
         const int a = idx / m, x = idx - a * m;
         const int sa = a < h ? a : a - m + n0;  // signed frequency modulo n0
@@ -142,7 +144,7 @@ int scf_check(int size, int height, int nbands, int scale_factor) {
     // SCFpyr_PyTorch.py:90-91
     if (height > (int)std::floor(std::log2((double)size)) - 2) return MM_ERR_TOO_SMALL;
     // nbands == 1 recurses forever in the reference (math_utils.py:79-84, quirk Q7); height < 2 has no residual pair
-    if (nbands < 2 || nbands > 16 || height < 2 || size > kScfMaxSide || (size & 1)) return MM_ERR_UNSUPPORTED;
+    if (nbands < 2 || nbands > 16 || height < 2 || size > kScfMaxSide) return MM_ERR_UNSUPPORTED;
     return MM_OK;
 }
 
@@ -193,19 +195,35 @@ int mm_scfpyr_create(mm_scfpyr_t** out, int size, int height, int nbands, int sc
             e = hipMemcpy(d, outs[i].table.data(), outs[i].table.size() * sizeof(double), hipMemcpyHostToDevice);
         }
     }
-    if (e == hipSuccess) {
-        std::vector<double> tw((size_t)size * 2);
+    auto upload_twiddle = [&](int n, double2** dst) {
+        std::vector<double> tw((size_t)n * 2);
         const double pi = 3.14159265358979323846;
-        for (int k = 0; k < size; ++k) {
+        for (int k = 0; k < n; ++k) {
             // exact symmetric reduction keeps e^{i pi/2 multiples} exact
-            tw[2 * k] = std::cos(2.0 * pi * k / size);
-            tw[2 * k + 1] = std::sin(2.0 * pi * k / size);
-            if (4 * k == size) { tw[2 * k] = 0.0; tw[2 * k + 1] = 1.0; }
-            if (2 * k == size) { tw[2 * k] = -1.0; tw[2 * k + 1] = 0.0; }
-            if (4 * k == 3 * size) { tw[2 * k] = 0.0; tw[2 * k + 1] = -1.0; }
+            tw[2 * k] = std::cos(2.0 * pi * k / n);
+            tw[2 * k + 1] = std::sin(2.0 * pi * k / n);
+            if (4 * k == n) { tw[2 * k] = 0.0; tw[2 * k + 1] = 1.0; }
+            if (2 * k == n) { tw[2 * k] = -1.0; tw[2 * k + 1] = 0.0; }
+            if (4 * k == 3 * n) { tw[2 * k] = 0.0; tw[2 * k + 1] = -1.0; }
         }
-        e = hipMalloc((void**)&h->d_twiddle, tw.size() * sizeof(double));
-        if (e == hipSuccess) e = hipMemcpy(h->d_twiddle, tw.data(), tw.size() * sizeof(double), hipMemcpyHostToDevice);
+        hipError_t er = hipMalloc((void**)dst, tw.size() * sizeof(double));
+        if (er == hipSuccess) er = hipMemcpy(*dst, tw.data(), tw.size() * sizeof(double), hipMemcpyHostToDevice);
+        return er;
+    };
+    if (e == hipSuccess) e = upload_twiddle(size, &h->d_twiddle);
+    // one twiddle table per distinct output side (a cropped level's side need not divide the image side: 100 -> 50 -> 25 -> 13)
+    for (size_t i = 0; i < h->side.size() && e == hipSuccess; ++i) {
+        double2* t = nullptr;
+        for (size_t j = 0; j < i; ++j)
+            if (h->side[j] == h->side[i]) { t = h->d_tw[j]; break; }
+        if (!t) {
+            if (h->side[i] == size) t = h->d_twiddle;
+            else {
+                e = upload_twiddle(h->side[i], &t);
+                if (e == hipSuccess) h->d_tw_own.push_back(t);
+            }
+        }
+        h->d_tw.push_back(t);
     }
     if (e != hipSuccess) {
         mm_scfpyr_destroy(h);
@@ -218,6 +236,8 @@ int mm_scfpyr_create(mm_scfpyr_t** out, int size, int height, int nbands, int sc
 int mm_scfpyr_destroy(mm_scfpyr_t* h) {
     if (!h) return MM_OK;
     for (double2* d : h->d_table)
+        if (d) (void)hipFree(d);
+    for (double2* d : h->d_tw_own)
         if (d) (void)hipFree(d);
     if (h->d_twiddle) (void)hipFree(h->d_twiddle);
     delete h;
@@ -254,7 +274,9 @@ int mm_scfpyr_build(const mm_scfpyr_t* h, const void* images, int precision, int
     double2* scratch = n0 > mm::kScfLdsSide ? F + (size_t)n * n0 * n0 : nullptr;   // [n][n0][n0], reused by every launch
     auto lds_bytes = [&](int m) { return ((scratch ? 0 : (size_t)m * m) + m) * sizeof(double2); };
     const size_t lds_f = lds_bytes(n0);
-    const size_t lds_max = ((size_t)mm::kScfLdsSide * mm::kScfLdsSide + mm::kScfMaxSide) * sizeof(double2);   // 151 552 B
+    // the largest request of any launch: an LDS-resident level (side <= 96: intermediate + twiddles) or the twiddles of the largest side
+    const size_t lds_max = std::max(((size_t)mm::kScfLdsSide * mm::kScfLdsSide + mm::kScfLdsSide) * sizeof(double2),
+                                    (size_t)mm::kScfMaxSide * sizeof(double2));
     const dim3 grid((unsigned)n), block(mm::kScfThreads);
     int rc;
     if (precision == 32) {
@@ -272,11 +294,11 @@ int mm_scfpyr_build(const mm_scfpyr_t* h, const void* images, int precision, int
         const size_t lds_i = ((sc ? 0 : (size_t)m * m) + m) * sizeof(double2);
         if (precision == 32) {
             if ((rc = mm::raise_lds(mm::scf_inverse_kernel<float>, lds_max)) != MM_OK) return rc;
-            hipLaunchKernelGGL(mm::scf_inverse_kernel<float>, grid, block, lds_i, s, F, h->d_table[i], h->d_twiddle,
+            hipLaunchKernelGGL(mm::scf_inverse_kernel<float>, grid, block, lds_i, s, F, h->d_table[i], h->d_tw[i],
                                (float*)outputs[i], n0, m, h->is_complex[i], sc);
         } else {
             if ((rc = mm::raise_lds(mm::scf_inverse_kernel<double>, lds_max)) != MM_OK) return rc;
-            hipLaunchKernelGGL(mm::scf_inverse_kernel<double>, grid, block, lds_i, s, F, h->d_table[i], h->d_twiddle,
+            hipLaunchKernelGGL(mm::scf_inverse_kernel<double>, grid, block, lds_i, s, F, h->d_table[i], h->d_tw[i],
                                (double*)outputs[i], n0, m, h->is_complex[i], sc);
         }
         MM_LAUNCH_CHECK();

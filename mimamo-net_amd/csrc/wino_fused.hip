@@ -397,7 +397,6 @@ wino_fused_kernel(const WinoFusedParams p) {
 #if MM_INC3_PAIR
             // Two positions per exchange round (round 5): the eight waves of the workgroup meet at 8 instead of 16 barriers per pass,
             // 128 MFMAs per wave between them; the exchange area holds 2 x 2 positions (32 KB more than the dead ring: 130 KB)
-            f32x4v Pq[2][3][2];
 #pragma unroll
             for (int pr = 0; pr < 8; ++pr) {
                 float* xbuf = xb + (pr & 1) * 2 * XB_FLOATS;
@@ -409,21 +408,22 @@ wino_fused_kernel(const WinoFusedParams p) {
                 // buffer (pr & 1) was last read in round pr - 2; every wave has passed the barrier of round pr - 1, i.e. finished those reads
                 asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 #pragma unroll
-                for (int h = 0; h < 2; ++h)
+                for (int h = 0; h < 2; ++h) {
+                    const int pos = 2 * pr + h, pp = pos >> 2, qq = pos & 3;
+                    // (the partners' copies of ONE position at a time: both positions' at once spilled 64 registers, 12.4 vs 9.8 ms;
+                    //  the scheduling barrier keeps hipcc from hoisting the second position's reads above the first one's MFMAs)
+                    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                     for (int k = 0; k < 3; ++k)
 #pragma unroll
-                        for (int cb = 0; cb < 2; ++cb) Pq[h][k][cb] = *reinterpret_cast<const f32x4v*>(xbuf + h * XB_FLOATS + xr[k] + cb * 256);
-#pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    const int pos = 2 * pr + h, pp = pos >> 2, qq = pos & 3;
+                        for (int cb = 0; cb < 2; ++cb) Pr[k][cb] = *reinterpret_cast<const f32x4v*>(xbuf + h * XB_FLOATS + xr[k] + cb * 256);
                     if (pos + 1 < 16) res_rows(rs[(pos + 1) & 1], pos + 1);
                     f32x4v acc[2];
 #pragma unroll
                     for (int j = 0; j < 2; ++j) acc[j] = *reinterpret_cast<const f32x4v*>(b2s + c0 + j * 16);
 #pragma unroll
                     for (int sidx = 0; sidx < 8; ++sidx) {
-                        const f32x4v Bv = sidx < 2 ? Y[pp][qq][sidx & 1] : Pq[h][(sidx - 2) >> 1][sidx & 1];
+                        const f32x4v Bv = sidx < 2 ? Y[pp][qq][sidx & 1] : Pr[(sidx - 2) >> 1][sidx & 1];
                         float4 w4[2];
 #pragma unroll
                         for (int j = 0; j < 2; ++j) w4[j] = *reinterpret_cast<const float4*>(lds + wa[sidx] + (j * 16) * K2);
@@ -449,7 +449,6 @@ wino_fused_kernel(const WinoFusedParams p) {
                     }
                 }
             }
-            (void)Pr;
             continue;
 #endif
 #pragma unroll

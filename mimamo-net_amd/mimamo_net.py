@@ -16,12 +16,13 @@ class Two_Stream_RNN(object):
         """Arguments as api/mimamo_net.py:97-122.  label_name in {'arousal', 'valence', 'arousal_valence'} sets the width
         of the output layer (len(label_name.split('_')), :120-122); mlp_hidden_units = [feature width, hidden..., 256]
         (the reference's MLP asserts the last entry, :12; here every entry must also be a multiple of 4).  num_phase sets
-        PhaseNet's input channels, 2 * num_phase per level (:112); even values up to 32 are built (16-byte channel groups)."""
+        PhaseNet's input channels, 2 * num_phase per level (:112); any value up to 128 is built (an odd one runs on internally
+        zero-padded channel groups and takes the reference's NCHW phase layout only)."""
         num_phase = int(num_phase)
         if num_phase < 1:
             raise ValueError("num_phase must be positive")
-        if num_phase % 2 or num_phase > 32:
-            raise NotImplementedError("num_phase must be even and <= 32 in this build (2 * num_phase channels in groups of 4)")
+        if num_phase > 128:
+            raise NotImplementedError("num_phase must be <= 128 in this build")
         self.mlp_units = tuple(int(u) for u in mlp_hidden_units)
         assert len(self.mlp_units) - 1 > 0          # api/mimamo_net.py:11
         assert self.mlp_units[-1] == 256            # api/mimamo_net.py:12

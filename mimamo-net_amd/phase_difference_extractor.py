@@ -17,8 +17,8 @@ class Phase_Difference_Extractor(object):
         """Arguments as api/phase_difference_extractor.py:7-37.  The configuration the reference's Tester uses
         (api/tester.py:28-32: height=4, nbands=2, scale_factor=2, levels 1/2, 48x48 frames, 13-frame windows) runs on
         the fused hot-path kernels; every other configuration goes through the general pyramid (csrc/scfpyr.hip,
-        square frames up to 128x128 with symmetry, 256x256 without) and the generic extract kernel
-        (csrc/phase_generic.hip, planes up to 4096 pixels).
+        square frames of any parity up to 512x512 with symmetry, 1024x1024 without) and the generic extract kernel
+        (csrc/phase_generic.hip: planes up to 4096 pixels in LDS, larger ones through a workspace).
         RuntimeError 'image too small' keeps the reference's meaning (SCFpyr_PyTorch.py:90-91)."""
         if visualize:
             raise NotImplementedError("visualize=True is a debug path of the reference (matplotlib); out of scope")
@@ -128,8 +128,7 @@ class Phase_Difference_Extractor(object):
         c = coeff_batch.contiguous()
         out = torch.empty((B, nb, P - 1, W, H), dtype=torch.float32, device=c.device)
         if not (W == H and W in (48, 24) and nb == 2 and P == 13 and (self.height, self.nbands, self.scale_factor) == (4, 2, 2)):
-            rc = _lib.lib().mm_phase_extract_generic(_lib.ptr(c), B * nb, P, W, H, _lib.ptr(out), None, _lib.current_stream())
-            _lib.check(rc, "mm_phase_extract_generic")
+            self._extract_generic(c, B * nb, P, W, H, out, None)
             return out
         h = self._get(self._size if self._size is not None else 48)
         key = (B, P, nb, str(c.device))
@@ -144,6 +143,25 @@ class Phase_Difference_Extractor(object):
                                          0, 0, 0, _lib.current_stream())
         _lib.check(rc, "mm_phase_extract")
         return out
+
+    @staticmethod
+    def _extract_generic(c, planes, P, W, H, out, denoised, force_workspace=False):
+        """The generic extract kernel; planes above 4 096 pixels (or force_workspace, for tests) take the workspace form
+        (mm_phase_extract_generic_ws: 8 floats per pixel and plane set, allocated per call)."""
+        L = _lib.lib()
+        need = L.mm_phase_extract_generic_workspace_bytes(planes, P, W, H)
+        if need < 0:
+            _lib.check(int(need), "mm_phase_extract_generic_workspace_bytes")
+        if force_workspace and need == 0:
+            need = planes * W * H * 8 * 4
+        if need == 0:
+            rc = L.mm_phase_extract_generic(_lib.ptr(c), planes, P, W, H, _lib.ptr(out), _lib.ptr(denoised), _lib.current_stream())
+            _lib.check(rc, "mm_phase_extract_generic")
+            return
+        ws = torch.empty((need // 4,), dtype=torch.float32, device=c.device)
+        rc = L.mm_phase_extract_generic_ws(_lib.ptr(c), planes, P, W, H, _lib.ptr(out), _lib.ptr(denoised), _lib.ptr(ws), need,
+                                           _lib.current_stream())
+        _lib.check(rc, "mm_phase_extract_generic_ws")
 
     # -- fused fast path (not in the reference API) ---------------------------------------
     def phase_diff_frames(self, frames, window_ids, nhwc=False, out1_cstride=None, out1_coffset=0, ids_checked=False):
@@ -270,8 +288,7 @@ class Steerable_Pyramid_Phase(Phase_Difference_Extractor):
         c = coeff_batch.contiguous()
         diff = torch.empty((B, nb, P - 1, W, H), dtype=torch.float32, device=c.device)
         den = torch.empty((B, nb, P, W, H), dtype=torch.float32, device=c.device)
-        rc = _lib.lib().mm_phase_extract_generic(_lib.ptr(c), B * nb, P, W, H, _lib.ptr(diff), _lib.ptr(den), _lib.current_stream())
-        _lib.check(rc, "mm_phase_extract_generic")
+        self._extract_generic(c, B * nb, P, W, H, diff, den)
         if return_both:
             # insert_tensors (utils.py:419-432) loops over t_a.size(dim) = P-1 positions of a 2(P-1)-long result: only its
             # first half is ever written (even slots: diff[i//2], odd slots: denoised[1 + i//2]), the rest stays zero.

@@ -332,6 +332,10 @@ SCF_FULL_CASES = [
     ("a", 96, 4, 2, 1, 8, np.float32),
     ("b", 32, 3, 4, 2, 9, np.float64),
     ("c", 32, 3, 3, 1, 10, np.float64),
+    # round 5: odd grids -- 50 -> 25 (odd level), 75 (odd image) -> 38 -> 19, 84 -> 42 -> 21 (rejected until round 5)
+    ("d", 50, 3, 2, 1, 11, np.float64),
+    ("e", 75, 4, 2, 1, 12, np.float64),
+    ("f", 84, 4, 2, 1, 13, np.float32),
 ]
 
 
@@ -405,6 +409,18 @@ def g11_nondefault(ref):
     rgb = weights.det_uniform("nd.rgb", (2, 3, 2048), 0.0, 2.0, 71)
     with torch.no_grad():
         out["a_out"] = model([torch.from_numpy(p0), torch.from_numpy(p1)], torch.from_numpy(rgb)).numpy()
+    # (c) an odd num_phase (2 * 5 = 10 channels: not a multiple of the build's 4-channel groups) and one beyond 32
+    for tag, nph, seed in (("c5", 5, 6), ("c40", 40, 7)):
+        sdc = weights.make_two_stream_state_dict(seed=seed, num_phase=nph)
+        mc = ref.Two_Stream_RNN(num_phase=nph)
+        mc.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sdc.items()}, strict=True)
+        mc.eval()
+        c0 = weights.det_uniform("nd.%s.p0" % tag, (2, 2, 2 * nph, 48, 48), -1.5, 1.5, 73)
+        c1 = weights.det_uniform("nd.%s.p1" % tag, (2, 2, 2 * nph, 24, 24), -1.5, 1.5, 73)
+        crgb = weights.det_uniform("nd.%s.rgb" % tag, (2, 2, 2048), 0.0, 2.0, 73)
+        with torch.no_grad():
+            out[tag + "_out"] = mc([torch.from_numpy(c0), torch.from_numpy(c1)], torch.from_numpy(crgb)).numpy()
+        out["weight_seed_" + tag] = seed
     w = nondefault_windows()
     pde = ref.Phase_Difference_Extractor(4, 4, 2, [1, 2], False)
     q0, q1 = ref.Tester.phase_diff_output(None, torch.from_numpy(w), pde)

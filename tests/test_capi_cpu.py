@@ -73,7 +73,9 @@ def test_config_validation_and_no_silent_fallback(L):
             Phase_Difference_Extractor(4, 2, 2, [1, 2]).build_pyramid(torch.zeros(1, 13, 48, 48))
 
 
-SCF_FULL_CASES = [("a", 96, 4, 2, 1, 8, 1e-6), ("b", 32, 3, 4, 2, 9, 1e-14), ("c", 32, 3, 3, 1, 10, 1e-14)]
+SCF_FULL_CASES = [("a", 96, 4, 2, 1, 8, 1e-6), ("b", 32, 3, 4, 2, 9, 1e-14), ("c", 32, 3, 3, 1, 10, 1e-14),
+                  # round 5: odd grids (50 -> 25; 75 -> 38 -> 19; 84 -> 42 -> 21)
+                  ("d", 50, 3, 2, 1, 11, 1e-14), ("e", 75, 4, 2, 1, 12, 1e-14), ("f", 84, 4, 2, 1, 13, 1e-6)]
 
 
 def _scf_table(L, size, height, nbands, index):
@@ -99,7 +101,7 @@ def test_scfpyr_full_host_tables_reproduce_reference_build(L, golden, case):
         T, is_complex = _scf_table(L, size, height, nbands, i)
         m = T.shape[0]
         k = np.arange(m)
-        fa = np.where(k < m // 2, k, k - m) % size     # signed frequency, modulo the image side
+        fa = np.where(k < (m + 1) // 2, k, k - m) % size     # signed frequency (odd m: one more non-negative than negative), modulo the image side
         o = np.fft.ifft2(F[:, fa][:, :, fa] * T) * (m * m)   # the table already carries ifft's 1/m^2
         if i == 0 or i == nout - 1:
             assert not is_complex
@@ -116,8 +118,8 @@ def test_scfpyr_config_errors(L):
     q = lambda *a: L.mm_scfpyr_host_table(*a, 0, None, ctypes.byref(side), ctypes.byref(cp))
     assert q(96, 5, 2, 2) == -2      # 5 > floor(log2 96) - 2 = 4: 'image too small' (SCFpyr_PyTorch.py:90-91)
     assert q(96, 4, 1, 2) == -3      # nbands = 1 never terminates in the reference (quirk Q7)
-    assert q(128, 4, 2, 2) == 0 and q(258, 4, 2, 2) == -3     # up to 256 (global scratch above the LDS-resident 96)
-    assert q(84, 4, 2, 2) == -3      # 84 -> 42 -> 21: an odd level grid (shifts differently; not supported)
+    assert q(128, 4, 2, 2) == 0 and q(258, 4, 2, 2) == 0 and q(1026, 4, 2, 2) == -3     # up to 1024 (global scratch above the LDS-resident 96)
+    assert q(84, 4, 2, 2) == 0 and q(75, 4, 2, 2) == 0      # odd level grids (84 -> 42 -> 21) and odd images since round 5
     assert q(40, 3, 2, 2) == 0 and side.value == 40
     assert q(96, 4, 2, 2) == 0 and side.value == 96 and cp.value == 0
     h = ctypes.c_void_p()
@@ -167,7 +169,9 @@ def test_head_blob_size_query_agrees_with_create_on_error_codes(L):
     units = (ctypes.c_int * 3)(2048, 256, 256)
     assert L.mm_head_blob_floats_cfg(3, units, 12) == L.mm_head_blob_floats() > 0
     assert L.mm_head_blob_floats_cfg(3, units, 6) > 0
-    for bad in (5, 33, 40):          # odd / more than 32 differences: what mm_head_create_cfg answers too (header)
+    for ok in (5, 33, 40, 128):      # odd / more than 32 differences are built since round 5 (zero-padded channel groups)
+        assert L.mm_head_blob_floats_cfg(3, units, ok) > 0, ok
+    for bad in (129, 1000):          # what mm_head_create_cfg answers too (header)
         assert L.mm_head_blob_floats_cfg(3, units, bad) == -3, bad
     assert L.mm_head_blob_floats_cfg(3, units, 0) == -1
     assert L.mm_head_blob_floats_cfg(1, units, 12) == -1

@@ -294,9 +294,45 @@ def test_head_with_another_num_phase_vs_real_reference(golden, oracle, dev):
            phase_layout="nhwc").cpu().numpy()
     assert np.abs(y2 - y).max() < 1e-6
     with pytest.raises(NotImplementedError):
-        Two_Stream_RNN(num_phase=7)
+        Two_Stream_RNN(num_phase=129)
     with pytest.raises(RuntimeError, match="size mismatch"):
         Two_Stream_RNN(num_phase=6).load_state_dict(weights.make_two_stream_state_dict(seed=0))
+
+
+@pytest.mark.parametrize("nph", [5, 40, 1])
+def test_head_with_odd_and_large_num_phase(golden, oracle, dev, nph):
+    """Round-4 verdict, missing item 3: Two_Stream_RNN(num_phase=p) for odd p (2 p channels are not a multiple of the build's 16-byte
+    channel groups: the phase buffers carry zero channels that meet zero weights) and p > 32 (64 + 2 p > 128: the concat layer runs in
+    the direct form instead of the fused Winograd kernel) against the REAL reference class (tests/golden/nondefault.npz, make_golden.py
+    g11 (c)) and against the oracle on a full clip."""
+    from mimamo_net_amd.mimamo_net import Two_Stream_RNN
+    g = golden("nondefault")
+    t = lambda a: torch.from_numpy(a).to(dev)
+    if nph in (5, 40):
+        tag = "c%d" % nph
+        sd = weights.make_two_stream_state_dict(seed=int(g["weight_seed_" + tag]), num_phase=nph)
+        m = Two_Stream_RNN(num_phase=nph).load_state_dict(sd).eval().to(dev)
+        c0 = weights.det_uniform("nd.%s.p0" % tag, (2, 2, 2 * nph, 48, 48), -1.5, 1.5, 73)
+        c1 = weights.det_uniform("nd.%s.p1" % tag, (2, 2, 2 * nph, 24, 24), -1.5, 1.5, 73)
+        rgb = weights.det_uniform("nd.%s.rgb" % tag, (2, 2, 2048), 0.0, 2.0, 73)
+        y = m([t(c0), t(c1)], t(rgb)).cpu().numpy()
+        err = np.abs(y - g[tag + "_out"]).max()
+        print("num_phase=%d head vs real reference: %.2e" % (nph, err))
+        assert err < OUT_ATOL and err < 6e-5, err
+    sd = weights.make_two_stream_state_dict(seed=11, num_phase=nph)
+    m = Two_Stream_RNN(num_phase=nph).load_state_dict(sd).eval().to(dev)
+    p0 = weights.det_uniform("oddp.p0", (1, 64, 2 * nph, 48, 48), -2.0, 2.0, 12)
+    p1 = weights.det_uniform("oddp.p1", (1, 64, 2 * nph, 24, 24), -2.0, 2.0, 12)
+    rgb = weights.det_uniform("oddp.rgb", (1, 64, 2048), 0.0, 2.0, 12)
+    want = oracle.two_stream_forward(sd, p0, p1, rgb)
+    got = m([t(p0), t(p1)], t(rgb)).cpu().numpy()
+    err = np.abs(got - want).max()
+    print("num_phase=%d head vs oracle, 64-frame clip: %.2e" % (nph, err))
+    assert err < OUT_ATOL and err < 3e-5, err
+    if nph % 2:          # channels-last inputs need whole 16-byte channel groups: refused for an odd num_phase, loudly
+        with pytest.raises(NotImplementedError):
+            m([t(p0).view(64, 2 * nph, 48, 48).permute(0, 2, 3, 1).contiguous(), t(p1).view(64, 2 * nph, 24, 24).permute(0, 2, 3, 1).contiguous()],
+              t(rgb), phase_layout="nhwc")
 
 
 def test_head_bs1_is_frame_permutation_equivariant(head, dev):
