@@ -768,10 +768,71 @@ def extra_legs(args, comp, ids0, n_frames):
                                    "snippets; unique frames counted once (snippet rows: %d per video)"
                                    % (len(plan["videos"][0]["ranges"]) * plan["videos"][0]["T"])}
     del vids
+    ex["bf16x3"] = bf16x3_leg(comp, ids0, n_frames, timeit)
     # (c) per-stage rates for the other single-GPU BASELINE configurations (SURVEY 8(d) "also per-stage frames/s")
     ex["phase_only"] = phase_only_leg(comp)
     ex["resnet50_only"] = resnet50_only_leg(comp)
     return ex
+
+
+PEAK_BF16_MFMA_TFLOPS = 2500.0   # MI355X_MICROARCH.md: dense bf16 MFMA (v_mfma_f32_32x32x16_bf16), measured 2 495
+
+
+def bf16x3_leg(comp, ids0, n_frames, timeit):
+    """OPTIONAL, never the headline (the reference computes in fp32; `dtype` of the line stays f32): the same step with the 1x1 layers of
+    K >= 512 -- conv3_x's reduce convs, conv4_x / conv5_x's 1x1 layers and projection contractions, conv5_x's Winograd position GEMMs -- on the
+    bf16 matrix pipes through a three-way bf16 split of both fp32 operands (6 of the 9 partial products, fp32 accumulate;
+    mm_resnet50_set_precision, csrc/conv_mfma.hip X3).  Reported against the bf16 roof next to the native-fp32 time of the same launches."""
+    from mimamo_net_amd import _lib
+    import tempfile
+    import shutil
+    hot, L = comp.hot, _lib.lib()
+
+    def x3_launches():
+        """(ms, algorithmic FLOPs, launches) of the layers the mode touches, from one single-stream step under the measurement hook"""
+        d = tempfile.mkdtemp(prefix="mm_prof_x3_")
+        os.environ["MM_PROF_DUMP"] = os.path.join(d, "l.csv")
+        ms, wk, ln = (ctypes.c_double * 5)(), (ctypes.c_double * 5)(), (ctypes.c_int64 * 5)()
+        with torch.no_grad():
+            comp.step(ids0, lanes=1)
+            comp.sync()
+            L.mm_profile_begin()
+            comp.step(ids0, lanes=1)
+            L.mm_profile_end(ms, wk, ln)
+        os.environ.pop("MM_PROF_DUMP", None)
+        rows = []
+        with open(os.path.join(d, "l.csv")) as f:
+            for line in f:
+                c_, w_, t_, tag_ = line.rstrip("\n").split(",", 3)
+                rows.append((int(c_), float(w_), float(t_), tag_))
+        shutil.rmtree(d, ignore_errors=True)
+        return rows, ms[0]
+
+    with torch.no_grad():
+        ref = comp.step(ids0, lanes=1).clone()
+    rows32, conv32 = x3_launches()
+    hot.resnet.set_precision("bf16x3")
+    try:
+        dt = timeit(lambda: comp.step(ids0))
+        with torch.no_grad():
+            out = comp.step(ids0, lanes=1)
+        diff = float((out - ref).abs().max())
+        rows, conv_x3 = x3_launches()
+    finally:
+        hot.resnet.set_precision("fp32")
+    sel = [r for r in rows if r[3].endswith(" x3")]
+    keys = {r[3][:-3] for r in sel}
+    sel32 = [r for r in rows32 if r[0] == 0 and r[3] in keys]
+    fl, ms = sum(r[1] for r in sel), sum(r[2] for r in sel)
+    ms32 = sum(r[2] for r in sel32)
+    return {"value": n_frames / dt, "unit": "frames/s", "ms_per_step": dt * 1e3, "dtype": "bf16x3 (fp32 in / out / accumulate)",
+            "max_abs_diff_vs_fp32_outputs": diff, "conv_launches_ms": conv_x3, "conv_launches_ms_fp32": conv32,
+            "layers": {"launches": len(sel), "algorithmic_flops": fl, "ms": ms, "ms_fp32_mfma": ms32,
+                       "fp32_equivalent_TFLOP_per_s": fl / (ms * 1e-3) / 1e12 if ms else None,
+                       "bf16_executed_TFLOP_per_s": 6 * fl / (ms * 1e-3) / 1e12 if ms else None,
+                       "frac_of_bf16_mfma_peak": 6 * fl / (ms * 1e-3) / 1e12 / PEAK_BF16_MFMA_TFLOPS if ms else None},
+            "what": "NOT the headline: same step, 1x1 layers with K >= 512 as six bf16 MFMA products of three-way split fp32 operands "
+                    "(fp32 accumulate); everything else fp32 as in the headline"}
 
 
 def _time_stream(fn, budget_s=1.0, min_iters=3):

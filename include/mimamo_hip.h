@@ -210,6 +210,13 @@ int64_t mm_resnet50_workspace_bytes(mm_resnet50_t* h, int64_t batch);
  * already normalised (255*x - mean, api/utils/model_utils.py:36-39).  out: [batch, 2048]
  * = relu(pool5_7x7_s1) on the device (the reference copies it to a CPU tensor and squeeze()s
  * it -- quirk Q8, not reproduced). */
+/* Arithmetic of the 1x1 layers with K >= 512 (conv3_x's 512 -> 128 reduce convs, all of conv4_x / conv5_x's 1x1 layers and projection
+ * contractions, conv5_x's Winograd position GEMMs).  0 (default, the headline and every parity claim): fp32 operands on the fp32 matrix
+ * pipes (v_mfma_f32_32x32x2_f32), bit-for-bit an fmaf chain.  1: both fp32 operands split three ways into bf16 in registers
+ * (x = h + m + l, 3 x 8 mantissa bits) and six of the nine partial products accumulated in fp32 on v_mfma_f32_32x32x16_bf16 (16 x the
+ * fp32-MFMA rate; the dropped terms are below 2^-24 relative).  Inputs, outputs, weights and every other layer stay fp32.  Reported by
+ * bench.py as extra.bf16x3 against the bf16 roof -- never as the headline (the reference computes in fp32). */
+int mm_resnet50_set_precision(mm_resnet50_t* h, int mode);
 int mm_resnet50_forward(mm_resnet50_t* h, const float* images, int nchw, int64_t batch, float* out,
                         void* workspace, int64_t workspace_bytes, void* stream);
 

@@ -52,6 +52,7 @@ SIGNATURES = {
     "mm_resnet50_create": (_i, [_c.POINTER(_vp), _vp, _i64, _i, _i, _f]),
     "mm_resnet50_destroy": (_i, [_vp]),
     "mm_resnet50_set_winograd": (_i, [_vp, _i]),
+    "mm_resnet50_set_precision": (_i, [_vp, _i]),
     "mm_resnet50_workspace_bytes": (_i64, [_vp, _i64]),
     "mm_resnet50_forward": (_i, [_vp, _vp, _i, _i64, _vp, _vp, _i64, _vp]),
     "mm_head_blob_floats": (_i64, []),

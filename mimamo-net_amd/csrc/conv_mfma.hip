@@ -31,11 +31,44 @@
 #include <atomic>
 #include <cstdio>
 #include <cstdlib>
+#include <type_traits>
 #include "conv.h"
 
 namespace mm {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+// ---- X3 (round 5, `extra` only -- never the headline): fp32 operands split three ways into bf16 (x = h + m + l, every part the
+// round-to-nearest bf16 of what is left: 3 x 8 = 24 mantissa bits) and multiplied on the bf16 matrix pipes, which run at 16 x the
+// fp32-MFMA rate: a b ~= al bh + ah bl + am bm + am bh + ah bm + ah bh (six v_mfma_f32_32x32x16_bf16, fp32 accumulate, the three dropped
+// cross terms are < 2^-24 relative).  The split runs in registers on the fp32 fragments the fp32 loop reads (same LDS image, same DMA,
+// same epilogue: the bf16 32x32x16 C layout is the fp32 32x32x2 one), 5.5 VALU instructions per element.
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned cvt_pk_bf16(float lo, float hi) {      // v_cvt_pk_bf16_f32 (round to nearest even), lo in bits 0..15
+    const f32x2 v = {lo, hi};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
+}
+__device__ __forceinline__ float sub_f32(float a, float b) {
+    float r;
+    asm("v_sub_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ void split_bf16x3(const float4& q0, const float4& q1, u32x4& H, u32x4& M, u32x4& L) {
+    const float x[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        // (the subtractions go through inline asm so that hipcc's SLP vectoriser cannot pair them into v_pk_add_f32: packed fp32 VALU
+        //  next to MFMAs is an anti-lever on this chip -- cdna_hip_programming.md, and 4.03 vs 3.37 ms measured on the 512 -> 128 layers)
+        const unsigned h = cvt_pk_bf16(x[2 * p], x[2 * p + 1]);
+        const float r0 = sub_f32(x[2 * p], __uint_as_float(h << 16)), r1 = sub_f32(x[2 * p + 1], __uint_as_float(h & 0xffff0000u));   // exact
+        const unsigned m = cvt_pk_bf16(r0, r1);
+        const float s0 = sub_f32(r0, __uint_as_float(m << 16)), s1 = sub_f32(r1, __uint_as_float(m & 0xffff0000u));                   // exact
+        H[p] = h; M[p] = m; L[p] = cvt_pk_bf16(s0, s1);
+    }
+}
 
 constexpr int CBK = 16;   // k-chunk
 constexpr int CLD = 16;   // LDS row = one 16-float chunk; the four 16-byte slots of a row are XOR-swizzled
@@ -55,8 +88,10 @@ constexpr int CLD = 16;   // LDS row = one 16-float chunk; the four 16-byte slot
 //      -- and the three floats past a row group meet zero weights.  No border logic: pad must be 0.
 //   6  1x1 kernel over TWO inputs (ConvParams::in2): chunks [0, Cin/16) come from `in`, the rest from `in2` sampled at stride2 --
 //      increase conv + projection shortcut of a residual block in one accumulation (the chunk -> source choice is wave-uniform)
-template <int BM, int BN, int WGM, int WGN, int KMODE, bool ABL = false>
-__global__ void __launch_bounds__(WGM * WGN * 64)
+// (the bf16x3 instantiations are held to the occupancy of their fp32 twins: the eight-wave one needs 133 registers where 128 keep two
+//  workgroups on a CU; the four-wave 128x256 one -- 64x128 wave tiles -- 280 where 256 keep two waves on a SIMD)
+template <int BM, int BN, int WGM, int WGN, int KMODE, bool ABL = false, bool X3 = false>
+__global__ void __launch_bounds__(WGM * WGN * 64) __attribute__((amdgpu_waves_per_eu(X3 ? (WGM * WGN == 8 ? 4 : 2) : 1, 8)))
 conv_mfma_kernel(const ConvParams p) {
     constexpr int NW = WGM * WGN;                     // waves per workgroup: 4, or 8 for the 128x256 tile
     static_assert(NW == 4 || NW == 8, "four or eight waves per workgroup");
@@ -321,6 +356,39 @@ conv_mfma_kernel(const ConvParams p) {
             tap_offsets();
         }
         if (ABL && (p.ablate & 64)) __builtin_amdgcn_s_setprio(1);
+        if constexpr (X3) {
+            // a lane's two float4 are k = 8 lh .. 8 lh + 7 of its row: exactly the 8 bf16 the 32x32x16 MFMA takes from it
+            u32x4 Ah[TM], Am[TM], Al[TM];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) split_bf16x3(fa[i][0], fa[i][1], Ah[i], Am[i], Al[i]);
+            auto mm16 = [](const u32x4& a, const u32x4& b, f32x16 c) {
+                return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+            };
+            // the A fragments stay split; the B fragments are split one column tile at a time (a 64 x 128 wave tile would not hold all of
+            // them).  Smallest terms first into the running fp32 accumulators; the TM sub-tiles of a column are independent chains.
+            // (two column tiles at a time: one long split block, then one long MFMA block; a block per column tile measured slower, and so
+            //  did a software-pipelined loop that places the split of chunk kc between the MFMAs of chunk kc - 1 -- 160-176 against
+            //  182-204 TFLOP/s-equivalent, profiles/r05_bf16x3_variants.txt.  tools/probes/valu_mfma_overlap.hip: on a gfx950 SIMD a block
+            //  of these split instructions and a block of bf16 MFMAs take the SUM of their times whichever waves they belong to, so the
+            //  mode is bound by VALU issue + MFMA time, ~1.4 x the fp32-MFMA rate instead of the 2.7 x six bf16 products could give)
+#pragma unroll
+            for (int j0 = 0; j0 < TN; j0 += 2) {
+                constexpr int JN = TN < 2 ? TN : 2;
+                u32x4 Bh[JN], Bm[JN], Bl[JN];
+#pragma unroll
+                for (int jj = 0; jj < JN; ++jj) split_bf16x3(fb[j0 + jj][0], fb[j0 + jj][1], Bh[jj], Bm[jj], Bl[jj]);
+#pragma unroll
+                for (int t = 0; t < 6; ++t)
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int jj = 0; jj < JN; ++jj) {
+                            const u32x4& a = t == 0 ? Al[i] : t == 1 ? Ah[i] : t == 2 ? Am[i] : t == 3 ? Am[i] : Ah[i];
+                            const u32x4& b = t == 0 ? Bh[jj] : t == 1 ? Bl[jj] : t == 2 ? Bm[jj] : t == 3 ? Bh[jj] : t == 4 ? Bm[jj] : Bh[jj];
+                            acc[i][j0 + jj] = mm16(a, b, acc[i][j0 + jj]);
+                        }
+            }
+        } else
 #pragma unroll
         for (int h = 0; h < 2; ++h)
 #pragma unroll
@@ -466,7 +534,7 @@ static int num_cus() {
     return v;
 }
 
-template <int BM, int BN, int WGM, int WGN, int KMODE, bool ABL = false>
+template <int BM, int BN, int WGM, int WGN, int KMODE, bool ABL = false, bool X3 = false>
 static int launch_km(ConvParams p, hipStream_t stream) {
     p.tiles_m = (p.M - p.m_off + BM - 1) / BM;
     p.tiles_n = (p.Cout + BN - 1) / BN;
@@ -475,10 +543,10 @@ static int launch_km(ConvParams p, hipStream_t stream) {
     if (blocks <= 0 || blocks > 0x7fffffff) return MM_ERR_INVALID_ARG;
     if (prof_enabled()) {
         char tag[64];
-        snprintf(tag, sizeof(tag), "M=%d K=%d N=%d k%d s%d t%dx%d b%d", p.M - p.m_off, p.K, p.Cout, p.kh, p.stride, BM, BN, p.batch);
+        snprintf(tag, sizeof(tag), "M=%d K=%d N=%d k%d s%d t%dx%d b%d%s", p.M - p.m_off, p.K, p.Cout, p.kh, p.stride, BM, BN, p.batch, X3 ? " x3" : "");
         prof_before(0, 2.0 * (double)(p.M - p.m_off) * (double)(p.kh * p.kw * p.Cin_real) * (double)p.Cout * (double)p.batch, stream, tag);
     }
-    hipLaunchKernelGGL((conv_mfma_kernel<BM, BN, WGM, WGN, KMODE, ABL>), dim3((unsigned)blocks), dim3(WGM * WGN * 64), 0, stream, p);
+    hipLaunchKernelGGL((conv_mfma_kernel<BM, BN, WGM, WGN, KMODE, ABL, X3>), dim3((unsigned)blocks), dim3(WGM * WGN * 64), 0, stream, p);
     prof_after(0, stream);
     MM_LAUNCH_CHECK();
     return MM_OK;
@@ -487,6 +555,10 @@ static int launch_km(ConvParams p, hipStream_t stream) {
 template <int BM, int BN, int WGM, int WGN>
 static int launch_cfg(const ConvParams& p, hipStream_t stream) {
     if (p.korder == 2) return launch_km<BM, BN, WGM, WGN, 5>(p, stream);
+    if constexpr (BN >= 64 && BM != 256) {      // the bf16x3 instantiations exist for the 1x1 forms on the 64x64 / 128x128 tiles (and 128x256 below)
+        if (p.x3 && p.in2) return launch_km<BM, BN, WGM, WGN, 6, false, true>(p, stream);
+        if (p.x3 && p.kh == 1 && p.kw == 1 && p.pad == 0) return launch_km<BM, BN, WGM, WGN, 3, false, true>(p, stream);
+    }
     if (p.in2) return launch_km<BM, BN, WGM, WGN, 6>(p, stream);
     if (p.kh == 1 && p.kw == 1 && p.pad == 0) return launch_km<BM, BN, WGM, WGN, 3>(p, stream);
     if (p.korder == 1) return launch_km<BM, BN, WGM, WGN, 1>(p, stream);
@@ -522,6 +594,7 @@ int conv_forward(const ConvParams& p0, hipStream_t stream) {
         const int64_t span = 256 / (hw_o > 0 ? hw_o : 1) + 2;
         if (span * p.H2 * p.W2 * p.in2_cstride * 4 >= 0x7FFFF000ll) return MM_ERR_INVALID_ARG;
     }
+    if (p.x3 && !(p.kh == 1 && p.kw == 1 && p.pad == 0 && p.korder == 0)) p.x3 = 0;   // bf16x3 exists for the 1x1 forms only
     p.M = p.B * p.Ho * p.Wo;
     if (p.m_end > 0 && p.m_end < p.M) p.M = p.m_end;            // (the bulk launch of a tail split ends early)
     if (p.M <= p.m_off) return MM_OK;
@@ -564,7 +637,7 @@ int conv_forward(const ConvParams& p0, hipStream_t stream) {
     // for launches of three or more full rounds: the lanes of the default pipeline run a third of the batch each (two rounds of the
     // 1024 -> 256 layer), and there another lane's kernels already fill a tail -- splitting those cost 0.6 ms per step.
     static const int split_on = getenv("MM_TAIL_SPLIT") ? atoi(getenv("MM_TAIL_SPLIT")) : 1;   // measurement knob
-    if (split_on && p.force_tile == 0 && (cfg == 5 || cfg == 1) && p.kh == 1 && p.kw == 1 && p.pad == 0 && p.batch <= 1 && p.m_off == 0) {
+    if (split_on && !p.x3 && p.force_tile == 0 && (cfg == 5 || cfg == 1) && p.kh == 1 && p.kw == 1 && p.pad == 0 && p.batch <= 1 && p.m_off == 0) {
         const int bm = 128, bn = cfg == 5 ? 256 : 128;
         const int occ = cfg == 5 ? (p.in2 ? occ_km<128, 256, 2, 4, 6>() : occ_km<128, 256, 2, 4, 3>())
                                  : (p.in2 ? occ_km<128, 128, 2, 2, 6>() : occ_km<128, 128, 2, 2, 3>());
@@ -593,6 +666,14 @@ int conv_forward(const ConvParams& p0, hipStream_t stream) {
         case 4: return launch_cfg<256, 64, 4, 1>(p, stream);
         case 5:   // 128x256, eight waves: the whole N of a 256-channel 1x1 layer in one workgroup (A read once)
             if (!(p.kh == 1 && p.kw == 1 && p.pad == 0)) return MM_ERR_INVALID_ARG;
+#ifndef MM_X3_WIDE
+#define MM_X3_WIDE 1   // 1: the bf16x3 form of the 128x256 tile runs on FOUR waves with 64x128 wave tiles (fewer split instructions per MFMA); 0: eight waves, 64x64
+#endif
+#if MM_X3_WIDE
+            if (p.x3) return p.in2 ? launch_km<128, 256, 2, 2, 6, false, true>(p, stream) : launch_km<128, 256, 2, 2, 3, false, true>(p, stream);
+#else
+            if (p.x3) return p.in2 ? launch_km<128, 256, 2, 4, 6, false, true>(p, stream) : launch_km<128, 256, 2, 4, 3, false, true>(p, stream);
+#endif
             if (p.in2) return launch_km<128, 256, 2, 4, 6>(p, stream);
             return launch_km<128, 256, 2, 4, 3>(p, stream);
         default: return MM_ERR_INVALID_ARG;

@@ -80,6 +80,11 @@ class Resnet50_Extractor(object):
         mode = {True: 1, False: 0}.get(mode, mode)
         _lib.check(_lib.lib().mm_resnet50_set_winograd(self._handle, int(mode)), "mm_resnet50_set_winograd")
 
+    def set_precision(self, mode="fp32"):
+        """"fp32" (default; the reference's arithmetic, the headline and every parity claim) or "bf16x3": the 1x1 layers with K >= 512
+        on the bf16 matrix pipes through a three-way bf16 split of both fp32 operands (mm_resnet50_set_precision; bench.py extra.bf16x3)."""
+        _lib.check(_lib.lib().mm_resnet50_set_precision(self._handle, {"fp32": 0, "bf16x3": 1}[mode]), "mm_resnet50_set_precision")
+
     def close(self):
         if getattr(self, "_handle", None) is not None:
             _lib.lib().mm_resnet50_destroy(self._handle)

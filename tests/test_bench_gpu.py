@@ -122,6 +122,7 @@ def test_default_line_has_the_contract_fields():
     ex = d["extra"]
     assert ex["direct_form"]["value"] > 0 and ex["multi_snippet"]["gru_seq_len"] == 5 and ex["multi_snippet"]["value"] > 0
     assert ex["streamed"]["value"] > 0 and ex["streamed"]["pcie_GB_per_s"] > 0
+    assert ex["bf16x3"]["value"] > 0 and ex["bf16x3"]["max_abs_diff_vs_fp32_outputs"] < 1e-4 and ex["bf16x3"]["layers"]["launches"] > 10
     # round 5: per-stage rates for BASELINE configs[1] / configs[2] in the driver-visible line
     for k in ("clips_32", "clips_256"):
         assert ex["phase_only"][k]["value"] > 1e5 and 0 < ex["phase_only"][k]["frac_of_hbm_peak"] < 1

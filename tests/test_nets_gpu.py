@@ -622,6 +622,31 @@ def test_resnet50_bn_eps_conv_bias_and_definition_file(oracle, dev, tmp_path):
     ext.close()
 
 
+def test_resnet50_bf16x3_mode(resnet, oracle, dev):
+    """mm_resnet50_set_precision(1) -- bench.py's extra.bf16x3, never the headline: the 1x1 layers with K >= 512 as six bf16 MFMA
+    products of three-way split fp32 operands.  pool5 against the fp32 oracle and against a float64 evaluation at the CONTRACT bounds
+    (the tight regression bounds belong to the fp32 path); switching back restores the fp32 bits."""
+    x = _images(3, 21)
+    xt = torch.from_numpy(x).to(dev)
+    sd = weights.make_resnet50_state_dict(seed=0)
+    want = oracle.resnet50_pool5(sd, x)
+    want64 = oracle.resnet50_pool5(sd, x.astype(np.float64), dtype=np.float64)
+    scale = np.abs(want64).max()
+    a = resnet.get_vec(xt).cpu().numpy()
+    resnet.set_precision("bf16x3")
+    try:
+        b = resnet.get_vec(xt).cpu().numpy()
+        b2 = resnet.get_vec(xt).cpu().numpy()
+    finally:
+        resnet.set_precision("fp32")
+    c = resnet.get_vec(xt).cpu().numpy()
+    assert np.array_equal(a, c) and np.array_equal(b, b2) and not np.array_equal(a, b)
+    for name, got in (("fp32", a), ("bf16x3", b)):
+        mx, mean = np.abs(got - want64).max() / scale, np.abs(got - want64).mean() / scale
+        print("pool5 %s vs float64: max rel %.2e mean rel %.2e; vs fp32 oracle max rel %.2e" % (name, mx, mean, np.abs(got - want).max() / scale))
+        assert mx < POOL5_RTOL * 10 and mean < POOL5_RTOL, (name, mx, mean)
+
+
 WINO_STRESS = {
     # BN gamma of reduce/3x3 in [0.5, 4] (8x per-channel dynamic range into every 3x3 layer), weakly damped increase
     # layers: activations of 1e3 .. 1e4 inside the blocks, pool5 ~ 1e3
@@ -663,6 +688,12 @@ def test_winograd_error_where_it_can_hurt(oracle, dev, case):
     for mode in (5, 4, 2, 0):
         ext.set_winograd(mode)
         rows["hip winograd %d" % mode] = ext.get_vec(xt).cpu().numpy()
+    # bench.py's extra.bf16x3 schedule (never the headline) on the same stress weights: default Winograd + the K >= 512 1x1 layers as six
+    # bf16 MFMA products of three-way split operands -- held to the CONTRACT bounds, reported next to the fp32 forms
+    ext.set_winograd(True)
+    ext.set_precision("bf16x3")
+    rows["hip bf16x3 (extra)"] = ext.get_vec(xt).cpu().numpy()
+    ext.set_precision("fp32")
     worst = {}
     print("\n[%s] pool5 |truth| max %.3e mean %.3e" % (case, scale, truth.mean()))
     for name, got in rows.items():
@@ -672,6 +703,8 @@ def test_winograd_error_where_it_can_hurt(oracle, dev, case):
         oe = np.abs(out - want_out).max()
         worst[name] = (e.max(), e.mean(), oe)
         print("  %-32s pool5 max rel %.2e mean rel %.2e | valence/arousal max abs err %.2e" % (name, e.max(), e.mean(), oe))
+    x3 = worst["hip bf16x3 (extra)"]
+    assert x3[0] < 1e-4 and x3[1] < 1e-5 and x3[2] < OUT_ATOL, x3
     d, w4, w2, w5 = worst["hip winograd 0"], worst["hip winograd 4"], worst["hip winograd 2"], worst["hip winograd 5"]
     assert w5[0] < 1e-4 and w5[1] < 1e-5 and w5[2] < OUT_ATOL, w5
     assert d[0] < 1e-4 and d[1] < 1e-5 and d[2] < OUT_ATOL, d                  # the direct form holds the stated bounds

@@ -19,6 +19,8 @@ mode = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 dev = torch.device("cuda:0")
 hot = HotPath(weights.make_two_stream_state_dict(0), weights.make_resnet50_state_dict(0), dev)
 hot.resnet.set_winograd(mode)
+if os.environ.get("LT_PRECISION"):          # e.g. LT_PRECISION=bf16x3 (bench.py's extra.bf16x3 schedule)
+    hot.resnet.set_precision(os.environ["LT_PRECISION"])
 one = synthetic.make_clip_u8(0, 64)
 frames = torch.from_numpy(np.concatenate([one] * clips)).to(dev)
 plan = hot.plan([64] * clips)
