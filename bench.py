@@ -821,8 +821,11 @@ def bf16x3_leg(comp, ids0, n_frames, timeit):
     finally:
         hot.resnet.set_precision("fp32")
     sel = [r for r in rows if r[3].endswith(" x3")]
-    keys = {r[3][:-3] for r in sel}
-    sel32 = [r for r in rows32 if r[0] == 0 and r[3] in keys]
+
+    def x3_layer(tag):           # the same layers in the fp32 schedule: 1x1 GEMM launches with K >= 512 (bulk + tail-split remainder rows)
+        f = dict(kv.split("=") for kv in tag.split() if "=" in kv)
+        return tag.startswith("M=") and " k1 " in tag + " " and int(f.get("K", 0)) >= 512
+    sel32 = [r for r in rows32 if r[0] == 0 and x3_layer(r[3])]
     fl, ms = sum(r[1] for r in sel), sum(r[2] for r in sel)
     ms32 = sum(r[2] for r in sel32)
     return {"value": n_frames / dt, "unit": "frames/s", "ms_per_step": dt * 1e3, "dtype": "bf16x3 (fp32 in / out / accumulate)",
