@@ -62,17 +62,19 @@ int wino_output_transform(const float* M, const float* bias, float* y, int B, in
 // F(4x4,3x3) position GEMMs + output transform in one kernel (wino_fused.hip): V [36][tiles][Cin] (wino_input_transform, m = 4),
 // U [36][Cout][Cin] -> y NHWC + bias, ReLU.  shape: workgroup variant (0 default, see wino_fused.hip; measurement knob).
 // Needs Cin % 64 == 0 and Cout % 32 == 0 (MM_ERR_UNSUPPORTED otherwise).
+// generic_loop (all three entry points): 1 = the runtime-scheduled main loop whatever K is; 0 (default) = the compile-time-scheduled one for
+// K = 64 / 128 / 256 (wino_fused.hip KSL: no address arithmetic left in a slab) -- same operations in the same order, bit-identical results
 int wino_gemm_output_fused(const float* V, const float* U, const float* bias, float* y, int B, int H, int W, int Cin, int Cout,
-                           int relu, int shape, hipStream_t s);
+                           int relu, int shape, hipStream_t s, int generic_loop = 0);
 // The same kernel with the residual block's 1x1 increase conv inside its epilogue -- (Cout, C2) == (64, 256): conv2_x blocks 2, 3, or
 // (128, 512): conv3_x blocks 2-4 (eight-wave workgroup):
 // out [B,H,W,C2] = relu( W2 relu(conv3x3(x) + bias) + bias2 + res ); the Cout-channel tensor in between never reaches HBM.
 int wino_gemm_output_fused_inc(const float* V, const float* U, const float* bias, const float* W2, const float* bias2, const float* res,
-                               float* out, int B, int H, int W, int Cin, int Cout, int C2, int relu, hipStream_t s);
+                               float* out, int B, int H, int W, int Cin, int Cout, int C2, int relu, hipStream_t s, int generic_loop = 0);
 bool wino_fused_inc_supported(int64_t ntile, int Cin, int Cout, int C2);
 // ... and with increase conv + stride-1 projection shortcut as one contraction over [relu(conv3x3) ; x] (conv2_x block 1): W2 [C2][128]
 int wino_gemm_output_fused_incproj(const float* V, const float* U, const float* bias, const float* W2, const float* bias2, const float* x,
-                                   float* out, int B, int H, int W, int Cin, int Cout, int C2, int relu, hipStream_t s);
+                                   float* out, int B, int H, int W, int Cin, int Cout, int C2, int relu, hipStream_t s, int generic_loop = 0);
 // whether wino_gemm_output_fused takes the shape (channel granularity, 32-bit offsets inside a position plane)
 bool wino_fused_supported(int64_t ntile, int Cin, int Cout);
 

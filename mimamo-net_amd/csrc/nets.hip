@@ -225,7 +225,7 @@ static int g_wino_fused_shape = 0;       // workgroup shape of the fused kernel,
 // [B,H,W,L.cout] -- inc_out = relu(inc([relu(L(in)); x])), no residual.
 static int run_layer_wino(const Layer& L, const float* in, int B, int H, int W, float* out, float* V, float* M, int m, hipStream_t s,
                           const Layer* inc = nullptr, const float* inc_res = nullptr, float* inc_out = nullptr, bool inc_two_src = false,
-                          int x3 = 0) {
+                          int x3 = 0, int generic_loop = 0) {
     const int mt = m == 5 ? 4 : m;
     const int TH = (H + mt - 1) / mt, TW = (W + mt - 1) / mt, npos = (mt + 2) * (mt + 2);
     const int64_t ntile = (int64_t)B * TH * TW;
@@ -244,12 +244,12 @@ static int run_layer_wino(const Layer& L, const float* in, int B, int H, int W, 
     if (rc != MM_OK) return rc;
     if (inc && inc_two_src)
         return wino_gemm_output_fused_incproj(V, L.wino_u4, L.bias, inc->w, inc->bias, inc_res, inc_out, B, H, W, wc, L.cout, inc->cout,
-                                              L.relu, s);
+                                              L.relu, s, generic_loop);
     if (inc)
         return wino_gemm_output_fused_inc(V, L.wino_u4, L.bias, inc->w, inc->bias, inc_res, inc_out, B, H, W, wc, L.cout, inc->cout,
-                                          L.relu, s);
+                                          L.relu, s, generic_loop);
     if (fused) {
-        rc = wino_gemm_output_fused(V, L.wino_u4, L.bias, out, B, H, W, wc, L.cout, L.relu, g_wino_fused_shape, s);
+        rc = wino_gemm_output_fused(V, L.wino_u4, L.bias, out, B, H, W, wc, L.cout, L.relu, g_wino_fused_shape, s, generic_loop);
         if (rc != MM_ERR_UNSUPPORTED) return rc;
     }
     if (!M) return MM_ERR_UNSUPPORTED;  // caller provided no plane set for the three-kernel form
@@ -299,6 +299,7 @@ struct mm_resnet50 {
     int winograd;  // 0 direct, 2 = F(2x2,3x3), 4 = F(4x4,3x3) for the layers that have Winograd-domain weights
     int fuse_proj; // 1 (default): the first block of a stage runs increase + projection as one launch
     int fuse_pool; // 1 (default): pool1 and conv2_1's 1x1 reduce conv run as one kernel (pool_reduce.hip)
+    int wf_generic;// MM_WF_KSL=0 at create time: the fused Winograd kernels' runtime-scheduled main loop (the parity twin of round 5's compile-time one)
     int precision; // 0 (default): every contraction on the fp32 matrix pipes; 1: 1x1 layers with K >= 512 through the three-way bf16 split
                    // (mm_resnet50_set_precision; bench.py's extra.bf16x3 -- never the headline)
     int fuse_inc;  // 3x3 + increase conv (+ residual | + projection) in ONE kernel (wino_fused.hip INC): 0 = never (the parity twin), 1 = conv2_x
@@ -419,6 +420,8 @@ int mm_resnet50_create(mm_resnet50_t** out, const float* blob, int64_t n_floats,
     h->winograd = 1;
     h->precision = 0;
     {
+        const char* wk = getenv("MM_WF_KSL");      // measurement knob / parity twin: 0 = the generic main loop in the fused Winograd kernels
+        h->wf_generic = wk ? atoi(wk) == 0 : 0;
         const char* fp = getenv("MM_FUSE_PROJ");   // measurement knob: 0 = projection shortcut as its own launch + residual read
         h->fuse_proj = fp ? atoi(fp) : 1;
         const char* fpl = getenv("MM_FUSE_POOL");  // measurement knob: 0 = max-pool and conv2_1's reduce conv as two launches (the parity twin)
@@ -600,14 +603,14 @@ int mm_resnet50_forward(mm_resnet50_t* h, const float* images, int nchw, int64_t
             if (wm_ == 5 && h->fuse_inc && !Bk.has_proj && (Bk.conv3.cout == 64 || h->fuse_inc >= 3)) {
                 // conv2_x blocks 2, 3 (Cin = Cout = 64 -> 256) and, with MM_FUSE_INC >= 3, conv3_x blocks 2-4 (128 -> 512): 3x3 +
                 // increase + residual + ReLU in one kernel
-                rc = run_layer_wino(Bk.conv3, y1, B, H1, W1, nullptr, wv, nullptr, 5, s, &Bk.increase, x, o);
+                rc = run_layer_wino(Bk.conv3, y1, B, H1, W1, nullptr, wv, nullptr, 5, s, &Bk.increase, x, o, false, 0, h->wf_generic);
                 inc_done = rc == MM_OK;
             } else if (wm_ == 5 && h->fuse_inc >= 2 && dual && Bk.proj_stride == 1 && C == Bk.conv3.cout && H1 == H && W1 == W) {
                 // conv2_x block 1: 3x3 + (increase | projection of the block input) + ReLU in one kernel
-                rc = run_layer_wino(Bk.conv3, y1, B, H1, W1, nullptr, wv, nullptr, 5, s, &Bk.inc_proj, x, o, true);
+                rc = run_layer_wino(Bk.conv3, y1, B, H1, W1, nullptr, wv, nullptr, 5, s, &Bk.inc_proj, x, o, true, 0, h->wf_generic);
                 inc_done = rc == MM_OK;
             }
-            if (rc == MM_ERR_UNSUPPORTED) rc = run_layer_wino(Bk.conv3, y1, B, H1, W1, y2, wv, wm, wm_, s, nullptr, nullptr, nullptr, false, x3);
+            if (rc == MM_ERR_UNSUPPORTED) rc = run_layer_wino(Bk.conv3, y1, B, H1, W1, y2, wv, wm, wm_, s, nullptr, nullptr, nullptr, false, x3, h->wf_generic);
             H2 = H1; W2 = W1;
         } else {
             rc = run_layer(Bk.conv3, y1, B, H1, W1, Bk.reduce.cout, 0, y2, Bk.conv3.cout, 0, nullptr, 0, s, &H2, &W2);

@@ -47,6 +47,7 @@ struct WinoFusedParams {
     const float* bias2;  // [C2]
     const float* res;    // INC 1: residual, NHWC [B][H][W][C2].  INC 2: the block input x, NHWC [B][H][W][Cout] -- the second K source
     int C2;              // 256
+    int generic_loop;    // 1: the runtime-scheduled main loop whatever K is (the parity twin of the compile-time-scheduled one)
     int ablate;          // -DMM_MEASURE builds only (results wrong by construction): bit 0 = every workgroup reads the V rows of the first
                          // 1 024 tiles (L2-resident: the kernel without its V traffic), bit 1 = residual rows from the first 4 096 pixels
 };
@@ -70,7 +71,15 @@ static constexpr float kAtHost[4][6] = {{1, 1, 1, 1, 1, 0}, {0, 1, -1, 2, -2, 0}
 // WGN = 4 (INC 3, conv3_x blocks 2-4: Cin = Cout = 128, increase 128 -> 512): eight waves as 2 x 4, 32 tiles x 128 channels -- the
 // workgroup again owns every channel of its pixels -- one workgroup per CU (120 KB ring); the 256 KB increase matrix passes through
 // LDS in four row quarters.
-template <int NBUF, int WGM, int INC = 0, int WGN = 2>
+// KSL (round 5): K / 64 as a compile-time constant (1, 2, 4; 0 = any K, the round-2 loop).  tools/probes/valu_mfma_overlap.hip showed that VALU
+// instructions do not hide under MFMAs on gfx950 -- their issue time ADDS to the matrix time, in block form, between the MFMAs of a stream,
+// and across the waves of a SIMD alike -- so the per-slab address arithmetic of the loop is paid in matrix time: 12 v_lshl_add_u32 for the
+// fragment addresses (ring slot base + swizzled row offset) and 5-6 v_add_u32 for the DMA offsets (+ k offset) per 32 MFMAs.  With the slab
+// sequence of a column unrolled (6 positions x KSL slabs, a multiple of the 3 ring slots) the ring slot is a compile-time constant that
+// folds into the ds_read_b128 offset field and into the M0 immediates of the DMA, and the k offset rides in the buffer instruction's scalar
+// offset: no VALU instruction is left in a slab besides the MFMAs and the output transform's updates.  Same operations on the same values in
+// the same order: bit-identical results (the KSL = 0 loop stays as the twin for any other K).
+template <int NBUF, int WGM, int INC = 0, int WGN = 2, int KSL = 0>
 __global__ void __launch_bounds__(WGM * WGN * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
 wino_fused_kernel(const WinoFusedParams p) {
     // WGM = 4: eight waves, 64 tiles x 64 channels, one workgroup per CU; WGM = 2: four waves, 32 tiles x 64 channels, two
@@ -227,6 +236,9 @@ wino_fused_kernel(const WinoFusedParams p) {
         }
     };
     auto update_y = [&](int qc) {
+        // (A^T's columns 0 and 5 are unit vectors -- three of their four FMAs per element multiply by zero -- but a workgroup-uniform branch
+        //  around them, like skipping the all-zero update of the first column, breaks the register allocation of the unrolled column body:
+        //  86-146 spilled registers in the KSL instantiations; built and dropped in round 5)
 #pragma unroll
         for (int qq = 0; qq < 4; ++qq) {
             const float c = p.at_cols[qc * 4 + qq];
@@ -286,6 +298,177 @@ wino_fused_kernel(const WinoFusedParams p) {
         buf = buf == NBUF - 1 ? 0 : buf + 1;
     };
 
+    if constexpr (KSL > 0) {
+        static_assert(NBUF == 3 && (6 * KSL) % NBUF == 0, "a column's slabs cover the ring a whole number of times");
+        constexpr int NSL = 6 * KSL;                         // slabs per column q
+        typedef __attribute__((address_space(3))) const f32x4v* lds_f4;      // (ext-vector type: HIP's float4 struct has no address-space-3 assignment on the host pass)
+        // LDS byte addresses of the fragment rows in ring slot 0; slot s adds s * SLAB_BYTES as an instruction offset
+        unsigned ab[4], bb0[4], bb1[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            ab[j] = lds0 + (unsigned)fa[j] * 4u;
+            bb0[j] = lds0 + (unsigned)fb0[j] * 4u;
+            bb1[j] = lds0 + (unsigned)fb1[j] * 4u;
+        }
+        const unsigned dbase = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)wave * 1024u);   // this wave's first piece in slot 0
+        int dq = 0;                                           // columns the DMA stream has finished
+        // DMA of the slab that is D slabs into the current column (D may run past the column's end: the stream is NBUF - 1 ahead)
+        auto dma_c = [&](auto d_tag) {
+            constexpr int D = decltype(d_tag)::value % NSL;
+            constexpr int DBUF = D % NBUF, DKS = D % KSL, DR = D / KSL;
+            constexpr unsigned SB = DBUF * SLAB_BYTES;
+            const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(pv), 0, rec_a, 0x00020000);
+            const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(pu), 0, rec_b, 0x00020000);
+            const unsigned ko = __builtin_amdgcn_readfirstlane(DKS * KS * 4);       // scalar offset of the buffer instruction
+            unsigned keep;
+            if constexpr (NIA == 2 && NIB == 4) {
+                asm volatile("s_mov_b32 %0, m0\n\t"
+                             "s_add_u32 m0, %9, %10\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %7, %16 offen lds\n\t"
+                             "s_add_u32 m0, %9, %11\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %7, %16 offen lds\n\t"
+                             "s_add_u32 m0, %9, %12\n\ts_nop 0\n\tbuffer_load_dwordx4 %3, %8, %16 offen lds\n\t"
+                             "s_add_u32 m0, %9, %13\n\ts_nop 0\n\tbuffer_load_dwordx4 %4, %8, %16 offen lds\n\t"
+                             "s_add_u32 m0, %9, %14\n\ts_nop 0\n\tbuffer_load_dwordx4 %5, %8, %16 offen lds\n\t"
+                             "s_add_u32 m0, %9, %15\n\ts_nop 0\n\tbuffer_load_dwordx4 %6, %8, %16 offen lds\n\t"
+                             "s_mov_b32 m0, %0"
+                             : "=&s"(keep)
+                             : "v"(va[0]), "v"(va[1]), "v"(vb[0]), "v"(vb[1]), "v"(vb[2]), "v"(vb[3]),
+                               "s"(ra), "s"(rb), "s"(dbase), "n"(SB), "n"(SB + NW * 1024), "n"(SB + BM * KS * 4), "n"(SB + BM * KS * 4 + NW * 1024),
+                               "n"(SB + BM * KS * 4 + 2 * NW * 1024), "n"(SB + BM * KS * 4 + 3 * NW * 1024), "s"(ko)
+                             : "memory", "scc");
+            } else if constexpr (NIA == 1 && NIB == 4) {
+                asm volatile("s_mov_b32 %0, m0\n\t"
+                             "s_add_u32 m0, %8, %9\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %6, %14 offen lds\n\t"
+                             "s_add_u32 m0, %8, %10\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %7, %14 offen lds\n\t"
+                             "s_add_u32 m0, %8, %11\n\ts_nop 0\n\tbuffer_load_dwordx4 %3, %7, %14 offen lds\n\t"
+                             "s_add_u32 m0, %8, %12\n\ts_nop 0\n\tbuffer_load_dwordx4 %4, %7, %14 offen lds\n\t"
+                             "s_add_u32 m0, %8, %13\n\ts_nop 0\n\tbuffer_load_dwordx4 %5, %7, %14 offen lds\n\t"
+                             "s_mov_b32 m0, %0"
+                             : "=&s"(keep)
+                             : "v"(va[0]), "v"(vb[0]), "v"(vb[1]), "v"(vb[2]), "v"(vb[3]),
+                               "s"(ra), "s"(rb), "s"(dbase), "n"(SB), "n"(SB + BM * KS * 4), "n"(SB + BM * KS * 4 + NW * 1024),
+                               "n"(SB + BM * KS * 4 + 2 * NW * 1024), "n"(SB + BM * KS * 4 + 3 * NW * 1024), "s"(ko)
+                             : "memory", "scc");
+            } else {
+                static_assert(NIA == 2 && NIB == 2, "piece counts of the workgroup shapes");
+                asm volatile("s_mov_b32 %0, m0\n\t"
+                             "s_add_u32 m0, %7, %8\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %5, %12 offen lds\n\t"
+                             "s_add_u32 m0, %7, %9\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %5, %12 offen lds\n\t"
+                             "s_add_u32 m0, %7, %10\n\ts_nop 0\n\tbuffer_load_dwordx4 %3, %6, %12 offen lds\n\t"
+                             "s_add_u32 m0, %7, %11\n\ts_nop 0\n\tbuffer_load_dwordx4 %4, %6, %12 offen lds\n\t"
+                             "s_mov_b32 m0, %0"
+                             : "=&s"(keep)
+                             : "v"(va[0]), "v"(va[1]), "v"(vb[0]), "v"(vb[1]), "s"(ra), "s"(rb), "s"(dbase), "n"(SB),
+                               "n"(SB + NW * 1024), "n"(SB + BM * KS * 4), "n"(SB + BM * KS * 4 + NW * 1024), "s"(ko)
+                             : "memory", "scc");
+            }
+            if constexpr (DKS == KSL - 1) {                    // that was the position's last slab: next position
+                pv += step_a;
+                pu += step_b;
+                if constexpr (DR == 5) {                       // ... and the column's last position: next column
+                    pv -= back_a;
+                    pu -= back_b;
+                    if (++dq == 6) rec_a = rec_b = 0;          // past the last slab: loads return zeros into a dead slot
+                }
+            }
+        };
+        auto slab_c = [&](auto n_tag) {
+            constexpr int N = decltype(n_tag)::value;          // slab index inside the column
+            constexpr int BUF = N % NBUF;
+            constexpr bool first = N % KSL == 0;
+            f32x4v (&Mc)[2] = M[(N / KSL) & 1];
+            asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" :: "n"((NBUF - 2) * NL) : "memory");
+            dma_c(std::integral_constant<int, N + NBUF - 1>());
+            if (first) Mc[0] = Mc[1] = f32x4v{0.f, 0.f, 0.f, 0.f};
+            if constexpr (INC) {
+                // the INC instantiations carry the epilogue's state through the loop: fragments in two halves (six reads, sixteen MFMAs
+                // each, pinned by a scheduling barrier) instead of all twelve up front -- with every address arithmetic gone hipcc would
+                // otherwise hoist all reads and spill 30 registers INSIDE the loop (scratch traffic would also break the counted vmcnt waits)
+#pragma unroll
+                for (int hh = 0; hh < 2; ++hh) {
+                    f32x4v a[2], b0[2], b1[2];
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        a[j] = *(lds_f4)(uintptr_t)(ab[2 * hh + j] + BUF * SLAB_BYTES);
+                        b0[j] = *(lds_f4)(uintptr_t)(bb0[2 * hh + j] + BUF * SLAB_BYTES);
+                        b1[j] = *(lds_f4)(uintptr_t)(bb1[2 * hh + j] + BUF * SLAB_BYTES);
+                    }
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        Mc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(b0[j].x, a[j].x, Mc[0], 0, 0, 0);
+                        Mc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(b1[j].x, a[j].x, Mc[1], 0, 0, 0);
+                        Mc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(b0[j].y, a[j].y, Mc[0], 0, 0, 0);
+                        Mc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(b1[j].y, a[j].y, Mc[1], 0, 0, 0);
+                        Mc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(b0[j].z, a[j].z, Mc[0], 0, 0, 0);
+                        Mc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(b1[j].z, a[j].z, Mc[1], 0, 0, 0);
+                        Mc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(b0[j].w, a[j].w, Mc[0], 0, 0, 0);
+                        Mc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(b1[j].w, a[j].w, Mc[1], 0, 0, 0);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            } else {
+            f32x4v a[4], b0[4], b1[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                a[j] = *(lds_f4)(uintptr_t)(ab[j] + BUF * SLAB_BYTES);
+                b0[j] = *(lds_f4)(uintptr_t)(bb0[j] + BUF * SLAB_BYTES);
+                b1[j] = *(lds_f4)(uintptr_t)(bb1[j] + BUF * SLAB_BYTES);
+            }
+            if constexpr (false) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    Mc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(b0[j].x, a[j].x, Mc[0], 0, 0, 0);
+                    Mc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(b1[j].x, a[j].x, Mc[1], 0, 0, 0);
+                    Mc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(b0[j].y, a[j].y, Mc[0], 0, 0, 0);
+                    Mc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(b1[j].y, a[j].y, Mc[1], 0, 0, 0);
+                    Mc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(b0[j].z, a[j].z, Mc[0], 0, 0, 0);
+                    Mc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(b1[j].z, a[j].z, Mc[1], 0, 0, 0);
+                    Mc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(b0[j].w, a[j].w, Mc[0], 0, 0, 0);
+                    Mc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(b1[j].w, a[j].w, Mc[1], 0, 0, 0);
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    Mc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j].x, b0[j].x, Mc[0], 0, 0, 0);
+                    Mc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j].x, b1[j].x, Mc[1], 0, 0, 0);
+                    Mc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j].y, b0[j].y, Mc[0], 0, 0, 0);
+                    Mc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j].y, b1[j].y, Mc[1], 0, 0, 0);
+                    Mc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j].z, b0[j].z, Mc[0], 0, 0, 0);
+                    Mc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j].z, b1[j].z, Mc[1], 0, 0, 0);
+                    Mc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j].w, b0[j].w, Mc[0], 0, 0, 0);
+                    Mc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j].w, b1[j].w, Mc[1], 0, 0, 0);
+                }
+            }
+            }
+        };
+        // the slabs of position r of a column (compile-time slab indices r * KSL .. r * KSL + KSL - 1)
+        auto position = [&](auto r_tag) {
+            constexpr int r = decltype(r_tag)::value;
+            slab_c(std::integral_constant<int, r * KSL>());
+            if constexpr (KSL > 1) slab_c(std::integral_constant<int, r * KSL + 1>());
+            if constexpr (KSL > 2) {
+                slab_c(std::integral_constant<int, r * KSL + 2>());
+                slab_c(std::integral_constant<int, r * KSL + 3>());
+            }
+            static_assert(KSL == 1 || KSL == 2 || KSL == 4, "K = 64, 128 or 256");
+        };
+        dma_c(std::integral_constant<int, 0>());
+        dma_c(std::integral_constant<int, 1>());
+        for (int q = 0; q < 6; ++q) {
+            position(std::integral_constant<int, 0>());
+            update_t(M[1], std::integral_constant<int, 5>());   // last row of the previous column (q = 0: zeros)
+            update_y(q == 0 ? 0 : q - 1);
+            position(std::integral_constant<int, 1>());
+            update_t(M[0], std::integral_constant<int, 0>());
+            position(std::integral_constant<int, 2>());
+            update_t(M[1], std::integral_constant<int, 1>());
+            position(std::integral_constant<int, 3>());
+            update_t(M[0], std::integral_constant<int, 2>());
+            position(std::integral_constant<int, 4>());
+            update_t(M[1], std::integral_constant<int, 3>());
+            position(std::integral_constant<int, 5>());
+            update_t(M[0], std::integral_constant<int, 4>());
+        }
+    } else {
 #pragma unroll
     for (int i = 0; i < NBUF - 1; ++i) dma_next();
     for (int q = 0; q < 6; ++q) {
@@ -310,6 +493,7 @@ wino_fused_kernel(const WinoFusedParams p) {
         slab(M[1], std::true_type());
         for (int ks = 1; ks < kslabs; ++ks) slab(M[1], std::false_type());
         update_t(M[0], std::integral_constant<int, 4>());
+    }
     }
     update_t(M[1], std::integral_constant<int, 5>());
     update_y(5);
@@ -779,8 +963,8 @@ wino_fused_kernel(const WinoFusedParams p) {
     }
 }
 
-template <int NBUF, int WGM, int INC = 0, int WGN = 2>
-static int launch_fused(WinoFusedParams p, hipStream_t s) {
+template <int NBUF, int WGM, int INC = 0, int WGN = 2, int KSL = 0>
+static int launch_fused_k(WinoFusedParams p, hipStream_t s) {
     constexpr int BM = 16 * WGM, BN = 32 * WGN;
     // INC: the increase matrix (64 KB) + exchange area (8 KB) take the dead operand ring, bias2 (1 KB) sits behind it: 73 KB, two
     // workgroups per CU still fit the 160 KB
@@ -791,7 +975,7 @@ static int launch_fused(WinoFusedParams p, hipStream_t s) {
     int dev = 0;
     (void)hipGetDevice(&dev);
     if (dev >= 0 && dev < 16 && !attr_set[dev]) {
-        MM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(wino_fused_kernel<NBUF, WGM, INC, WGN>), hipFuncAttributeMaxDynamicSharedMemorySize,
+        MM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(wino_fused_kernel<NBUF, WGM, INC, WGN, KSL>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                    LDS_BYTES));
         attr_set[dev] = true;
     }
@@ -803,7 +987,7 @@ static int launch_fused(WinoFusedParams p, hipStream_t s) {
     const int lds_bytes = LDS_BYTES + (INC ? lds_pad : 0);
     p.ablate = INC ? ablate : 0;
     if (INC && lds_pad)
-        MM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(wino_fused_kernel<NBUF, WGM, INC, WGN>), hipFuncAttributeMaxDynamicSharedMemorySize,
+        MM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(wino_fused_kernel<NBUF, WGM, INC, WGN, KSL>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                    lds_bytes));
 #else
     constexpr int lds_bytes = LDS_BYTES;
@@ -822,10 +1006,26 @@ static int launch_fused(WinoFusedParams p, hipStream_t s) {
         if (INC) fl += 2.0 * (double)p.B * p.H * p.W * (double)(INC == 2 ? 2 * p.Cout : p.Cout) * (double)p.C2;
         prof_before(0, fl, s, tag);
     }
-    hipLaunchKernelGGL((wino_fused_kernel<NBUF, WGM, INC, WGN>), dim3((unsigned)blocks), dim3(WGM * WGN * 64), lds_bytes, s, p);
+    hipLaunchKernelGGL((wino_fused_kernel<NBUF, WGM, INC, WGN, KSL>), dim3((unsigned)blocks), dim3(WGM * WGN * 64), lds_bytes, s, p);
     prof_after(0, s);
     MM_LAUNCH_CHECK();
     return MM_OK;
+}
+
+// K = 64 / 128 / 256 (every ResNet50 / PhaseNet layer that comes here) take the compile-time-scheduled loop, any other multiple of 64 -- and
+// every K when the caller asks for the twin (p.generic_loop: MM_WF_KSL=0 at create time, the parity twin) -- the generic one
+template <int NBUF, int WGM, int INC = 0, int WGN = 2>
+static int launch_fused(const WinoFusedParams& p, hipStream_t s) {
+    // (not the eight-wave shapes: their 40 KB slabs put ring slot 2 beyond the 16-bit ds_read offset, hipcc then adds the slot base per
+    //  read again -- and, no longer seeing the 16-byte alignment, splits every ds_read_b128 into two ds_read2_b32)
+    if constexpr (NBUF == 3 && WGM * WGN == 4) {
+        if (!p.generic_loop && p.K == 64) return launch_fused_k<NBUF, WGM, INC, WGN, 1>(p, s);
+        if constexpr (INC == 0) {      // the INC kernels exist for K = 64 only
+            if (!p.generic_loop && p.K == 128) return launch_fused_k<NBUF, WGM, INC, WGN, 2>(p, s);
+            if (!p.generic_loop && p.K == 256) return launch_fused_k<NBUF, WGM, INC, WGN, 4>(p, s);
+        }
+    }
+    return launch_fused_k<NBUF, WGM, INC, WGN, 0>(p, s);
 }
 
 bool wino_fused_supported(int64_t ntile, int Cin, int Cout) {
@@ -840,8 +1040,9 @@ bool wino_fused_inc_supported(int64_t ntile, int Cin, int Cout, int C2) {
 
 // V [36][ntile][Cin] (from wino_input_transform, m = 4), U [36][Cout][Cin] -> y NHWC [B,H,W,Cout] (+bias, ReLU)
 int wino_gemm_output_fused(const float* V, const float* U, const float* bias, float* y, int B, int H, int W, int Cin, int Cout,
-                            int relu, int shape, hipStream_t s) {
+                            int relu, int shape, hipStream_t s, int generic_loop) {
     WinoFusedParams p;
+    p.generic_loop = generic_loop;
     p.V = V; p.U = U; p.bias = bias; p.out = y;
     p.w2 = nullptr; p.bias2 = nullptr; p.res = nullptr; p.C2 = 0;
     p.TH = (H + 3) / 4; p.TW = (W + 3) / 4;
@@ -858,9 +1059,10 @@ int wino_gemm_output_fused(const float* V, const float* U, const float* bias, fl
 // The 3x3 layer AND the block's increase conv: V, U as above with Cout == 64;  out [B,H,W,C2] = relu( W2 relu(conv3x3 + bias) +
 // bias2 + res ), W2 [C2][64] (BN folded), res NHWC [B,H,W,C2], C2 == 256.  MM_ERR_UNSUPPORTED for any other shape.
 int wino_gemm_output_fused_inc(const float* V, const float* U, const float* bias, const float* W2, const float* bias2, const float* res,
-                               float* out, int B, int H, int W, int Cin, int Cout, int C2, int relu, hipStream_t s) {
+                               float* out, int B, int H, int W, int Cin, int Cout, int C2, int relu, hipStream_t s, int generic_loop) {
     if (!V || !U || !W2 || !bias2 || !res || !out) return MM_ERR_INVALID_ARG;
     WinoFusedParams p;
+    p.generic_loop = generic_loop;
     p.V = V; p.U = U; p.bias = bias; p.out = out;
     p.w2 = W2; p.bias2 = bias2; p.res = res; p.C2 = C2;
     p.TH = (H + 3) / 4; p.TW = (W + 3) / 4;
@@ -876,9 +1078,10 @@ int wino_gemm_output_fused_inc(const float* V, const float* U, const float* bias
 // out [B,H,W,C2] = relu( W2[:, :64] relu(conv3x3 + bias) + W2[:, 64:] x + bias2 ), W2 [C2][128] (make_layer_dual), x NHWC [B,H,W,64]
 // at the same pixels (stride-1 shortcut), C2 == 256.
 int wino_gemm_output_fused_incproj(const float* V, const float* U, const float* bias, const float* W2, const float* bias2, const float* x,
-                                   float* out, int B, int H, int W, int Cin, int Cout, int C2, int relu, hipStream_t s) {
+                                   float* out, int B, int H, int W, int Cin, int Cout, int C2, int relu, hipStream_t s, int generic_loop) {
     if (!V || !U || !W2 || !bias2 || !x || !out) return MM_ERR_INVALID_ARG;
     WinoFusedParams p;
+    p.generic_loop = generic_loop;
     p.V = V; p.U = U; p.bias = bias; p.out = out;
     p.w2 = W2; p.bias2 = bias2; p.res = x; p.C2 = C2;
     p.TH = (H + 3) / 4; p.TW = (W + 3) / 4;

@@ -622,6 +622,34 @@ def test_resnet50_bn_eps_conv_bias_and_definition_file(oracle, dev, tmp_path):
     ext.close()
 
 
+def test_fused_winograd_compile_time_scheduled_loop_is_bit_identical_to_the_generic_one(resnet, dev, monkeypatch):
+    """Round 5: for K = 64 / 128 / 256 the fused Winograd kernels run a main loop whose ring slots, k offsets and DMA destinations are
+    compile-time constants (no address arithmetic next to the MFMAs: VALU issue adds to matrix time on gfx950,
+    profiles/r05_valu_mfma_overlap.txt).  Same operations on the same values in the same order as the generic loop (MM_WF_KSL=0 at create
+    time): the pool5 features must be the same BITS -- default schedule, plain fused form (MM_FUSE_INC=0: K = 64 through the plain kernel)
+    and the all-fused mode, on a batch that does not fill the last tile."""
+    from mimamo_net_amd.resnet50_extractor import Resnet50_Extractor
+    sd = weights.make_resnet50_state_dict(seed=0)
+    xt = torch.from_numpy(_images(3, 31)).to(dev)
+    for inc in (None, "0"):
+        if inc is not None:
+            monkeypatch.setenv("MM_FUSE_INC", inc)
+        new = Resnet50_Extractor(state_dict=sd, device=dev)
+        monkeypatch.setenv("MM_WF_KSL", "0")
+        twin = Resnet50_Extractor(state_dict=sd, device=dev)
+        monkeypatch.delenv("MM_WF_KSL")
+        for mode in (True, 5):
+            new.set_winograd(mode)
+            twin.set_winograd(mode)
+            a, b = new.get_vec(xt), twin.get_vec(xt)
+            assert torch.equal(a, b), (inc, mode, (a - b).abs().max().item())
+        new.close()
+        twin.close()
+        if inc is not None:
+            monkeypatch.delenv("MM_FUSE_INC")
+    assert torch.equal(resnet.get_vec(xt), resnet.get_vec(xt))
+
+
 def test_resnet50_bf16x3_mode(resnet, oracle, dev):
     """mm_resnet50_set_precision(1) -- bench.py's extra.bf16x3, never the headline: the 1x1 layers with K >= 512 as six bf16 MFMA
     products of three-way split fp32 operands.  pool5 against the fp32 oracle and against a float64 evaluation at the CONTRACT bounds
