@@ -33,6 +33,8 @@ struct ConvParams {
     // or re-read).  in2 is NHWC [B, H2, W2, in2_cstride]; needs kh = kw = 1, pad = 0, stride = 1, Cin % 16 == 0, C2 % 16 == 0.
     const float* in2;
     int H2, W2, C2, in2_cstride, in2_coff, stride2;
+    int sched1x1;    // set by conv_forward: 1x1 layer with K % 16 == 0 on the scheduled loop (conv_mfma.hip KMODE 7 / 8)
+    int no_sched;    // 1: keep modes 3 / 6 for such a layer (the parity twin of the scheduled loop)
     int x3;          // 1: 1x1 layer on the bf16 matrix pipes through a three-way bf16 split of both fp32 operands (conv_mfma.hip X3; `extra` only)
 };
 

@@ -37,6 +37,16 @@
 namespace mm {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// compile-time loop: f(std::integral_constant<int, 0>()) ... f(std::integral_constant<int, N - 1>())
+template <int... I, class F>
+__device__ __forceinline__ void static_for_impl(std::integer_sequence<int, I...>, F&& f) {
+    (f(std::integral_constant<int, I>()), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+    static_for_impl(std::make_integer_sequence<int, N>(), f);
+}
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
@@ -88,10 +98,17 @@ constexpr int CLD = 16;   // LDS row = one 16-float chunk; the four 16-byte slot
 //      -- and the three floats past a row group meet zero weights.  No border logic: pad must be 0.
 //   6  1x1 kernel over TWO inputs (ConvParams::in2): chunks [0, Cin/16) come from `in`, the rest from `in2` sampled at stride2 --
 //      increase conv + projection shortcut of a residual block in one accumulation (the chunk -> source choice is wave-uniform)
-// (the bf16x3 instantiations are held to the occupancy of their fp32 twins: the eight-wave one needs 133 registers where 128 keep two
+//   7 / 8  (round 5) modes 3 / 6 for K % 16 == 0 with NO vector instruction left in the loop besides the MFMAs: the per-lane DMA offsets are
+//      loop constants and the k offset rides in the buffer instructions' SCALAR offset; the chunk loop is unrolled by the ring depth, so the
+//      ring slot is a compile-time constant that folds into the ds_read_b128 offset fields and into the M0 immediates of the DMA.  Why:
+//      tools/probes/valu_mfma_overlap.hip -- VALU issue time ADDS to matrix time on gfx950 (22 VALU instructions per 32 MFMAs in mode 3:
+//      fragment addresses, lane offsets + their out-of-range selects).  Same products in the same order: bit-identical to modes 3 / 6.
+// (the scheduled 1x1 loop of the 128x128 tile would take 188 registers -- every fragment read of a step in flight at once -- where its mode-3
+//  twin's 156 keep three workgroups on a CU: held to three waves per SIMD.  The bf16x3 instantiations are held to the occupancy of their fp32 twins: the eight-wave one needs 133 registers where 128 keep two
 //  workgroups on a CU; the four-wave 128x256 one -- 64x128 wave tiles -- 280 where 256 keep two waves on a SIMD)
 template <int BM, int BN, int WGM, int WGN, int KMODE, bool ABL = false, bool X3 = false>
-__global__ void __launch_bounds__(WGM * WGN * 64) __attribute__((amdgpu_waves_per_eu(X3 ? (WGM * WGN == 8 ? 4 : 2) : 1, 8)))
+__global__ void __launch_bounds__(WGM * WGN * 64)
+    __attribute__((amdgpu_waves_per_eu(X3 ? (WGM * WGN == 8 ? 4 : 2) : (KMODE >= 7 && WGM * WGN == 4 && BM * BN == 128 * 128) ? 3 : 1, 8)))
 conv_mfma_kernel(const ConvParams p) {
     constexpr int NW = WGM * WGN;                     // waves per workgroup: 4, or 8 for the 128x256 tile
     static_assert(NW == 4 || NW == 8, "four or eight waves per workgroup");
@@ -148,10 +165,10 @@ conv_mfma_kernel(const ConvParams p) {
     const __amdgpu_buffer_rsrc_t rsrc_b =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(w_b), 0, (unsigned)((int64_t)p.Cout * p.Kpad * 4), 0x00020000);
     constexpr unsigned OOB = 0xFFFFFFFFu;
-    const int64_t img_elems2 = KMODE == 6 ? (int64_t)p.H2 * p.W2 * p.in2_cstride : 0;
+    const int64_t img_elems2 = (KMODE == 6 || KMODE == 8) ? (int64_t)p.H2 * p.W2 * p.in2_cstride : 0;
     const int64_t rem_elems2 = ((int64_t)p.B - img0) * img_elems2;
     const unsigned a2_bytes = rem_elems2 * 4 > 0xFFFFF000ll ? 0xFFFFF000u : (unsigned)(rem_elems2 * 4);
-    const __amdgpu_buffer_rsrc_t rsrc_a2 = KMODE == 6
+    const __amdgpu_buffer_rsrc_t rsrc_a2 = (KMODE == 6 || KMODE == 8)
         ? __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.in2) + img0 * img_elems2, 0, a2_bytes, 0x00020000) : rsrc_a;
 
     // DMA lane mapping: wave w, instruction `it` covers rows (it*4 + w)*16 .. +15; lane l -> row + (l >> 2), slot l & 3
@@ -170,7 +187,7 @@ conv_mfma_kernel(const ConvParams p) {
         a_wi0[it] = wo * p.stride - p.pad;
         // element offset of tap (0,0), channel 0, relative to the descriptor base (may be negative: padding)
         a_pix[it] = (b - img0) * (int)img_elems + (a_hi0[it] * p.W + a_wi0[it]) * p.in_cstride + p.in_coff;
-        a_pix2[it] = KMODE == 6 ? (b - img0) * (int)img_elems2 + (ho * p.stride2 * p.W2 + wo * p.stride2) * p.in2_cstride + p.in2_coff - p.Cin
+        a_pix2[it] = (KMODE == 6 || KMODE == 8) ? (b - img0) * (int)img_elems2 + (ho * p.stride2 * p.W2 + wo * p.stride2) * p.in2_cstride + p.in2_coff - p.Cin
                                 : 0;   // - Cin: the second source is indexed with the running k
     }
     unsigned vb[BIT];
@@ -298,6 +315,102 @@ conv_mfma_kernel(const ConvParams p) {
 
     const int lr = lane & 31, lh = lane >> 5;
     const int nk = p.Kpad / CBK;
+    if constexpr (KMODE == 7 || KMODE == 8) {
+        static_assert(!ABL && !X3, "the scheduled 1x1 loop has no measurement / bf16x3 form");
+        // ---- loop-constant lane offsets (bytes; OOB = out of range for the hardware check, which looks at the vector offset only)
+        unsigned vac[AIT], vac2[AIT], vbc[BIT];
+#pragma unroll
+        for (int it = 0; it < AIT; ++it) {
+            vac[it] = a_ok[it] ? (unsigned)(a_pix[it] + kq * 4) * 4u : OOB;
+            vac2[it] = (KMODE == 8 && a_ok[it]) ? (unsigned)(a_pix2[it] + p.Cin + kq * 4) * 4u : OOB;   // a_pix2 carries - Cin for the running k of mode 6
+        }
+#pragma unroll
+        for (int it = 0; it < BIT; ++it) vbc[it] = vb[it];
+        // this wave's first piece in ring slot 0 of each operand
+        const unsigned wa0 = __builtin_amdgcn_readfirstlane(lds_a + (unsigned)(wave * 16 * CLD * 4));
+        const unsigned wb0 = __builtin_amdgcn_readfirstlane(lds_b + (unsigned)(wave * 16 * CLD * 4));
+        auto piece = [&](const __amdgpu_buffer_rsrc_t& rsrc, unsigned voff, unsigned soff, unsigned wbase, auto off_tag) {
+            unsigned keep;
+            asm volatile("s_mov_b32 %0, m0\n\ts_add_u32 m0, %4, %5\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep) : "v"(voff), "s"(rsrc), "s"(soff), "s"(wbase), "n"(decltype(off_tag)::value) : "memory", "scc");
+        };
+        int dch = 0;                                       // chunk the next DMA round fetches
+        auto dma_f = [&](auto dbuf_tag) {
+            constexpr int DBUF = decltype(dbuf_tag)::value;
+            // past the last chunk the scalar offset would leave the tensors (the range check does not see it): zero records instead
+            const unsigned live = dch < nk ? 0xFFFFFFFFu : 0u;
+            const bool second = KMODE == 8 && dch >= nk1;
+            const unsigned so_b = __builtin_amdgcn_readfirstlane((unsigned)dch * (CBK * 4u));
+            const unsigned so_a = __builtin_amdgcn_readfirstlane(second ? (unsigned)(dch - nk1) * (CBK * 4u) : (unsigned)dch * (CBK * 4u));
+            const __amdgpu_buffer_rsrc_t ra = second
+                ? __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.in2) + img0 * img_elems2, 0, a2_bytes & live, 0x00020000)
+                : __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(in_b) + img0 * img_elems, 0, a_bytes & live, 0x00020000);
+            const __amdgpu_buffer_rsrc_t rb =
+                __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(w_b), 0, (unsigned)((int64_t)p.Cout * p.Kpad * 4) & live, 0x00020000);
+            static_for<AIT>([&](auto it_tag) {
+                constexpr int IT = decltype(it_tag)::value;
+                piece(ra, (KMODE == 8 && second) ? vac2[IT] : vac[IT], so_a, wa0, std::integral_constant<int, (DBUF * BM + IT * RPR) * CLD * 4>());
+            });
+            static_for<BIT>([&](auto it_tag) {
+                constexpr int IT = decltype(it_tag)::value;
+                piece(rb, vbc[IT], so_b, wb0, std::integral_constant<int, (DBUF * BN + IT * RPR) * CLD * 4>());
+            });
+            ++dch;
+        };
+        // fragment addresses in ring slot 0 (floats); slot s adds s * BM (BN) * CLD as an instruction offset
+        int fao[TM][2], fbo[TN][2];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int r = wm * WM + i * 32 + lr, g = (r >> 2) & 3;
+            fao[i][0] = r * CLD + (((2 * lh) ^ g) << 2);
+            fao[i][1] = r * CLD + (((2 * lh + 1) ^ g) << 2);
+        }
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int r = wn * WN + j * 32 + lr, g = (r >> 2) & 3;
+            fbo[j][0] = r * CLD + (((2 * lh) ^ g) << 2);
+            fbo[j][1] = r * CLD + (((2 * lh + 1) ^ g) << 2);
+        }
+        auto step = [&](auto buf_tag) {
+            constexpr int BUF = decltype(buf_tag)::value;
+            dma_f(std::integral_constant<int, (BUF + 2) % NBUF>());
+            float4 qa[TM][2], qb[TN][2];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                qa[i][0] = *reinterpret_cast<const float4*>(As + BUF * BM * CLD + fao[i][0]);
+                qa[i][1] = *reinterpret_cast<const float4*>(As + BUF * BM * CLD + fao[i][1]);
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                qb[j][0] = *reinterpret_cast<const float4*>(Bs + BUF * BN * CLD + fbo[j][0]);
+                qb[j][1] = *reinterpret_cast<const float4*>(Bs + BUF * BN * CLD + fbo[j][1]);
+            }
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int j = 0; j < TN; ++j) {
+                            const float a = kk == 0 ? qa[i][h].x : kk == 1 ? qa[i][h].y : kk == 2 ? qa[i][h].z : qa[i][h].w;
+                            const float b = kk == 0 ? qb[j][h].x : kk == 1 ? qb[j][h].y : kk == 2 ? qb[j][h].z : qb[j][h].w;
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[i][j], 0, 0, 0);
+                        }
+            asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" :: "n"(NL) : "memory");
+        };
+        dma_f(std::integral_constant<int, 0>());
+        dma_f(std::integral_constant<int, 1>());
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" :: "n"(NL) : "memory");   // chunk 0 landed (chunk 1 still in flight)
+        int kc = 0;
+        for (; kc + NBUF <= nk; kc += NBUF) {
+            step(std::integral_constant<int, 0>());
+            step(std::integral_constant<int, 1>());
+            step(std::integral_constant<int, 2>());
+        }
+        if (nk - kc >= 1) step(std::integral_constant<int, 0>());
+        if (nk - kc == 2) step(std::integral_constant<int, 1>());
+    } else {
     tap_offsets();
     dma(0);
     tap_advance();
@@ -406,6 +519,7 @@ conv_mfma_kernel(const ConvParams p) {
             asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" :: "n"(NL) : "memory");
         buf = buf == NBUF - 1 ? 0 : buf + 1;
         buf2 = buf2 == NBUF - 1 ? 0 : buf2 + 1;
+    }
     }
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");   // drain the over-issued loads before LDS is re-used
 
@@ -559,6 +673,8 @@ static int launch_cfg(const ConvParams& p, hipStream_t stream) {
         if (p.x3 && p.in2) return launch_km<BM, BN, WGM, WGN, 6, false, true>(p, stream);
         if (p.x3 && p.kh == 1 && p.kw == 1 && p.pad == 0) return launch_km<BM, BN, WGM, WGN, 3, false, true>(p, stream);
     }
+    if (p.sched1x1 && p.in2) return launch_km<BM, BN, WGM, WGN, 8>(p, stream);
+    if (p.sched1x1) return launch_km<BM, BN, WGM, WGN, 7>(p, stream);
     if (p.in2) return launch_km<BM, BN, WGM, WGN, 6>(p, stream);
     if (p.kh == 1 && p.kw == 1 && p.pad == 0) return launch_km<BM, BN, WGM, WGN, 3>(p, stream);
     if (p.korder == 1) return launch_km<BM, BN, WGM, WGN, 1>(p, stream);
@@ -595,6 +711,12 @@ int conv_forward(const ConvParams& p0, hipStream_t stream) {
         if (span * p.H2 * p.W2 * p.in2_cstride * 4 >= 0x7FFFF000ll) return MM_ERR_INVALID_ARG;
     }
     if (p.x3 && !(p.kh == 1 && p.kw == 1 && p.pad == 0 && p.korder == 0)) p.x3 = 0;   // bf16x3 exists for the 1x1 forms only
+    // 1x1 layers whose K is a whole number of chunks take the scheduled loop (KMODE 7 / 8) unless the caller asks for modes 3 / 6 (no_sched:
+    // MM_CONV_SCHED=0 at mm_resnet50_create, the parity twin)
+#ifndef MM_SCHED_RES_MINK
+#define MM_SCHED_RES_MINK 512   // layers with a residual epilogue and a shorter K keep mode 3 (256 -> 1024 + residual measured 3 % SLOWER on the scheduled loop)
+#endif
+    p.sched1x1 = !p.no_sched && !p.x3 && !(p.res && p.K < MM_SCHED_RES_MINK) && p.kh == 1 && p.kw == 1 && p.pad == 0 && p.korder == 0 && p.K == p.Kpad && p.force_tile < 16;
     p.M = p.B * p.Ho * p.Wo;
     if (p.m_end > 0 && p.m_end < p.M) p.M = p.m_end;            // (the bulk launch of a tail split ends early)
     if (p.M <= p.m_off) return MM_OK;
@@ -674,6 +796,7 @@ int conv_forward(const ConvParams& p0, hipStream_t stream) {
 #else
             if (p.x3) return p.in2 ? launch_km<128, 256, 2, 4, 6, false, true>(p, stream) : launch_km<128, 256, 2, 4, 3, false, true>(p, stream);
 #endif
+            if (p.sched1x1) return p.in2 ? launch_km<128, 256, 2, 4, 8>(p, stream) : launch_km<128, 256, 2, 4, 7>(p, stream);
             if (p.in2) return launch_km<128, 256, 2, 4, 6>(p, stream);
             return launch_km<128, 256, 2, 4, 3>(p, stream);
         default: return MM_ERR_INVALID_ARG;

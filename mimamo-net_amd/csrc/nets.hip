@@ -182,7 +182,7 @@ constexpr int kX3MinK = 512;   // mm_resnet50_set_precision(h, 1): 1x1 layers wi
 
 static int run_layer(const Layer& L, const float* in, int B, int H, int W, int in_cstride, int in_coff, float* out,
                      int out_cstride, int out_coff, const float* res, int res_cstride, hipStream_t s, int* Ho_ = nullptr,
-                     int* Wo_ = nullptr, int x3 = 0) {
+                     int* Wo_ = nullptr, int x3 = 0, int no_sched = 0) {
     ConvParams p;
     std::memset(&p, 0, sizeof(p));
     p.in = in; p.w = L.w; p.bias = L.bias; p.res = res; p.post_scale = L.ps; p.post_shift = L.pt; p.out = out;
@@ -194,6 +194,7 @@ static int run_layer(const Layer& L, const float* in, int B, int H, int W, int i
     p.kh = L.k; p.kw = L.k; p.stride = L.stride; p.pad = L.pad;
     p.K = L.K; p.Kpad = L.Kpad; p.relu = L.relu; p.Cin_real = L.cin; p.korder = L.korder; p.force_tile = L.tile;
     p.x3 = x3 && L.k == 1 && L.Kpad >= kX3MinK;
+    p.no_sched = no_sched;
     if (Ho_) *Ho_ = p.Ho;
     if (Wo_) *Wo_ = p.Wo;
     return conv_forward(p, s);
@@ -203,7 +204,7 @@ static int run_layer(const Layer& L, const float* in, int B, int H, int W, int i
 // transform with the fused bias/ReLU.  V and M are caller-provided scratch of 16*B*ceil(H/2)*ceil(W/2)*C floats.
 // out = relu(L over [in | in2 sampled at stride2]); in [B,H,W,L.cin], in2 [B,H2,W2,C2]
 static int run_layer_dual(const Layer& L, const float* in, int B, int H, int W, const float* in2, int H2, int W2, int C2, int stride2,
-                          float* out, hipStream_t s, int x3 = 0) {
+                          float* out, hipStream_t s, int x3 = 0, int no_sched = 0) {
     ConvParams p;
     std::memset(&p, 0, sizeof(p));
     p.in = in; p.w = L.w; p.bias = L.bias; p.out = out;
@@ -212,6 +213,7 @@ static int run_layer_dual(const Layer& L, const float* in, int B, int H, int W, 
     p.K = L.K; p.Kpad = L.Kpad; p.relu = 1; p.Cin_real = L.K;
     p.in2 = in2; p.H2 = H2; p.W2 = W2; p.C2 = C2; p.in2_cstride = C2; p.stride2 = stride2;
     p.x3 = x3 && L.Kpad >= kX3MinK;
+    p.no_sched = no_sched;
     return conv_forward(p, s);
 }
 
@@ -225,7 +227,7 @@ static int g_wino_fused_shape = 0;       // workgroup shape of the fused kernel,
 // [B,H,W,L.cout] -- inc_out = relu(inc([relu(L(in)); x])), no residual.
 static int run_layer_wino(const Layer& L, const float* in, int B, int H, int W, float* out, float* V, float* M, int m, hipStream_t s,
                           const Layer* inc = nullptr, const float* inc_res = nullptr, float* inc_out = nullptr, bool inc_two_src = false,
-                          int x3 = 0, int generic_loop = 0) {
+                          int x3 = 0, int generic_loop = 0, int no_sched = 0) {
     const int mt = m == 5 ? 4 : m;
     const int TH = (H + mt - 1) / mt, TW = (W + mt - 1) / mt, npos = (mt + 2) * (mt + 2);
     const int64_t ntile = (int64_t)B * TH * TW;
@@ -260,6 +262,7 @@ static int run_layer_wino(const Layer& L, const float* in, int B, int H, int W, 
     p.Cout = L.cout; p.out_cstride = L.cout; p.kh = 1; p.kw = 1; p.stride = 1; p.K = wc; p.Kpad = wc; p.Cin_real = wc;
     p.batch = npos; p.in_bstride = ntile * wc; p.w_bstride = (int64_t)L.cout * wc; p.out_bstride = ntile * L.cout;
     p.x3 = x3 && wc >= kX3MinK;      // the position GEMMs of the three-kernel form (conv5_x: K = 512)
+    p.no_sched = no_sched;
     rc = conv_forward(p, s);
     if (rc != MM_OK) return rc;
     return wino_output_transform(M, L.bias, out, B, H, W, L.cout, L.relu, m, s);
@@ -299,6 +302,7 @@ struct mm_resnet50 {
     int winograd;  // 0 direct, 2 = F(2x2,3x3), 4 = F(4x4,3x3) for the layers that have Winograd-domain weights
     int fuse_proj; // 1 (default): the first block of a stage runs increase + projection as one launch
     int fuse_pool; // 1 (default): pool1 and conv2_1's 1x1 reduce conv run as one kernel (pool_reduce.hip)
+    int no_sched;  // MM_CONV_SCHED=0 at create time: 1x1 layers on the engine's modes 3 / 6 instead of the scheduled loop (modes 7 / 8): the parity twin
     int wf_generic;// MM_WF_KSL=0 at create time: the fused Winograd kernels' runtime-scheduled main loop (the parity twin of round 5's compile-time one)
     int precision; // 0 (default): every contraction on the fp32 matrix pipes; 1: 1x1 layers with K >= 512 through the three-way bf16 split
                    // (mm_resnet50_set_precision; bench.py's extra.bf16x3 -- never the headline)
@@ -422,6 +426,8 @@ int mm_resnet50_create(mm_resnet50_t** out, const float* blob, int64_t n_floats,
     {
         const char* wk = getenv("MM_WF_KSL");      // measurement knob / parity twin: 0 = the generic main loop in the fused Winograd kernels
         h->wf_generic = wk ? atoi(wk) == 0 : 0;
+        const char* cs = getenv("MM_CONV_SCHED");  // measurement knob / parity twin: 0 = no scheduled 1x1 loop in the conv engine
+        h->no_sched = cs ? atoi(cs) == 0 : 0;
         const char* fp = getenv("MM_FUSE_PROJ");   // measurement knob: 0 = projection shortcut as its own launch + residual read
         h->fuse_proj = fp ? atoi(fp) : 1;
         const char* fpl = getenv("MM_FUSE_POOL");  // measurement knob: 0 = max-pool and conv2_1's reduce conv as two launches (the parity twin)
@@ -573,7 +579,7 @@ int mm_resnet50_forward(mm_resnet50_t* h, const float* images, int nchw, int64_t
     H = Ho; W = Wo;
     int xi = 1;  // index of the buffer holding the block input
     int C = 64;
-    const int x3 = h->precision == 1;
+    const int x3 = h->precision == 1, ns = h->no_sched;
     for (const Bottleneck& Bk : h->blocks) {
         float* x = big[xi];
         float* sc = big[(xi + 1) % 3];
@@ -582,14 +588,14 @@ int mm_resnet50_forward(mm_resnet50_t* h, const float* images, int nchw, int64_t
         const float* resid = x;
         const bool dual = Bk.has_proj && h->fuse_proj && Bk.inc_proj.w;
         if (Bk.has_proj && !dual) {
-            rc = run_layer(Bk.proj, x, B, H, W, C, 0, sc, Bk.proj.cout, 0, nullptr, 0, s, nullptr, nullptr, x3);
+            rc = run_layer(Bk.proj, x, B, H, W, C, 0, sc, Bk.proj.cout, 0, nullptr, 0, s, nullptr, nullptr, x3, ns);
             if (rc != MM_OK) return rc;
             resid = sc;
         }
         if (pooled_reduce && &Bk == &h->blocks.front()) {
             H1 = H; W1 = W;                        // y1 was written by the pool kernel
         } else {
-            rc = run_layer(Bk.reduce, x, B, H, W, C, 0, y1, Bk.reduce.cout, 0, nullptr, 0, s, &H1, &W1, x3);
+            rc = run_layer(Bk.reduce, x, B, H, W, C, 0, y1, Bk.reduce.cout, 0, nullptr, 0, s, &H1, &W1, x3, ns);
             if (rc != MM_OK) return rc;
         }
         // default (1): conv2_x..conv4_x (Cin <= 256) take the fused kernel, conv5_x the three-kernel form (Cin = 512: its
@@ -610,7 +616,7 @@ int mm_resnet50_forward(mm_resnet50_t* h, const float* images, int nchw, int64_t
                 rc = run_layer_wino(Bk.conv3, y1, B, H1, W1, nullptr, wv, nullptr, 5, s, &Bk.inc_proj, x, o, true, 0, h->wf_generic);
                 inc_done = rc == MM_OK;
             }
-            if (rc == MM_ERR_UNSUPPORTED) rc = run_layer_wino(Bk.conv3, y1, B, H1, W1, y2, wv, wm, wm_, s, nullptr, nullptr, nullptr, false, x3, h->wf_generic);
+            if (rc == MM_ERR_UNSUPPORTED) rc = run_layer_wino(Bk.conv3, y1, B, H1, W1, y2, wv, wm, wm_, s, nullptr, nullptr, nullptr, false, x3, h->wf_generic, ns);
             H2 = H1; W2 = W1;
         } else {
             rc = run_layer(Bk.conv3, y1, B, H1, W1, Bk.reduce.cout, 0, y2, Bk.conv3.cout, 0, nullptr, 0, s, &H2, &W2);
@@ -620,10 +626,10 @@ int mm_resnet50_forward(mm_resnet50_t* h, const float* images, int nchw, int64_t
             H3 = H2; W3 = W2;
         } else if (dual) {
             // relu(BN(increase(y2)) + BN(proj(x))) in one accumulation: the shortcut tensor is never written or re-read
-            rc = run_layer_dual(Bk.inc_proj, y2, B, H2, W2, x, H, W, C, Bk.proj_stride, o, s, x3);
+            rc = run_layer_dual(Bk.inc_proj, y2, B, H2, W2, x, H, W, C, Bk.proj_stride, o, s, x3, ns);
             H3 = H2; W3 = W2;
         } else {
-            rc = run_layer(Bk.increase, y2, B, H2, W2, Bk.conv3.cout, 0, o, Bk.increase.cout, 0, resid, Bk.increase.cout, s, &H3, &W3, x3);
+            rc = run_layer(Bk.increase, y2, B, H2, W2, Bk.conv3.cout, 0, o, Bk.increase.cout, 0, resid, Bk.increase.cout, s, &H3, &W3, x3, ns);
         }
         if (rc != MM_OK) return rc;
         H = H3; W = W3; C = Bk.increase.cout;

@@ -371,7 +371,14 @@ wino_fused_kernel(const WinoFusedParams p) {
                 }
             }
         };
-        auto slab_c = [&](auto n_tag) {
+#ifndef MM_WF_HOOK
+#define MM_WF_HOOK 1      // 1: the pending output-transform updates run as ONE block between a slab's fragment reads and its MFMA burst (below)
+#endif
+        // `hook` (first slab of a position): the output-transform updates of the PREVIOUS position, placed between this slab's fragment
+        // reads and its MFMAs and pinned there by scheduling barriers -- one VALU block under the LDS latency, then 32 MFMAs back to back.
+        // Left to itself hipcc spreads those ~25-70 VALU instructions over the gaps of the MFMA burst; on gfx950 every MFMA -> VALU -> MFMA
+        // transition costs ~2.5 ns on top of the instructions themselves (tools/probes/valu_mfma_overlap.hip, interleaved vs block form).
+        auto slab_c = [&](auto n_tag, auto&& hook) {
             constexpr int N = decltype(n_tag)::value;          // slab index inside the column
             constexpr int BUF = N % NBUF;
             constexpr bool first = N % KSL == 0;
@@ -392,6 +399,7 @@ wino_fused_kernel(const WinoFusedParams p) {
                         b0[j] = *(lds_f4)(uintptr_t)(bb0[2 * hh + j] + BUF * SLAB_BYTES);
                         b1[j] = *(lds_f4)(uintptr_t)(bb1[2 * hh + j] + BUF * SLAB_BYTES);
                     }
+                    // (no hook here: the INC kernels measured 0.5-1 % slower with the transform block pinned, r05_ab_wino_loop.txt)
 #pragma unroll
                     for (int j = 0; j < 2; ++j) {
                         Mc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(b0[j].x, a[j].x, Mc[0], 0, 0, 0);
@@ -412,6 +420,11 @@ wino_fused_kernel(const WinoFusedParams p) {
                 a[j] = *(lds_f4)(uintptr_t)(ab[j] + BUF * SLAB_BYTES);
                 b0[j] = *(lds_f4)(uintptr_t)(bb0[j] + BUF * SLAB_BYTES);
                 b1[j] = *(lds_f4)(uintptr_t)(bb1[j] + BUF * SLAB_BYTES);
+            }
+            if (MM_WF_HOOK) {
+                __builtin_amdgcn_sched_barrier(0);
+                hook();
+                __builtin_amdgcn_sched_barrier(0);
             }
             if constexpr (false) {
 #pragma unroll
@@ -441,32 +454,44 @@ wino_fused_kernel(const WinoFusedParams p) {
             }
         };
         // the slabs of position r of a column (compile-time slab indices r * KSL .. r * KSL + KSL - 1)
-        auto position = [&](auto r_tag) {
+        auto nothing = []() {};
+        auto position = [&](auto r_tag, auto&& hook) {
             constexpr int r = decltype(r_tag)::value;
-            slab_c(std::integral_constant<int, r * KSL>());
-            if constexpr (KSL > 1) slab_c(std::integral_constant<int, r * KSL + 1>());
+            slab_c(std::integral_constant<int, r * KSL>(), hook);
+            if constexpr (KSL > 1) slab_c(std::integral_constant<int, r * KSL + 1>(), nothing);
             if constexpr (KSL > 2) {
-                slab_c(std::integral_constant<int, r * KSL + 2>());
-                slab_c(std::integral_constant<int, r * KSL + 3>());
+                slab_c(std::integral_constant<int, r * KSL + 2>(), nothing);
+                slab_c(std::integral_constant<int, r * KSL + 3>(), nothing);
             }
             static_assert(KSL == 1 || KSL == 2 || KSL == 4, "K = 64, 128 or 256");
         };
         dma_c(std::integral_constant<int, 0>());
         dma_c(std::integral_constant<int, 1>());
         for (int q = 0; q < 6; ++q) {
-            position(std::integral_constant<int, 0>());
+            if constexpr (MM_WF_HOOK && INC == 0) {
+            // position r's first slab carries the transform of position r - 1 (position 0: the previous column's last row, then that column
+            // into Y; q = 0: zeros)
+            position(std::integral_constant<int, 0>(), [&]() { update_t(M[1], std::integral_constant<int, 5>()); update_y(q == 0 ? 0 : q - 1); });
+            position(std::integral_constant<int, 1>(), [&]() { update_t(M[0], std::integral_constant<int, 0>()); });
+            position(std::integral_constant<int, 2>(), [&]() { update_t(M[1], std::integral_constant<int, 1>()); });
+            position(std::integral_constant<int, 3>(), [&]() { update_t(M[0], std::integral_constant<int, 2>()); });
+            position(std::integral_constant<int, 4>(), [&]() { update_t(M[1], std::integral_constant<int, 3>()); });
+            position(std::integral_constant<int, 5>(), [&]() { update_t(M[0], std::integral_constant<int, 4>()); });
+            } else {
+            position(std::integral_constant<int, 0>(), nothing);
             update_t(M[1], std::integral_constant<int, 5>());   // last row of the previous column (q = 0: zeros)
             update_y(q == 0 ? 0 : q - 1);
-            position(std::integral_constant<int, 1>());
+            position(std::integral_constant<int, 1>(), nothing);
             update_t(M[0], std::integral_constant<int, 0>());
-            position(std::integral_constant<int, 2>());
+            position(std::integral_constant<int, 2>(), nothing);
             update_t(M[1], std::integral_constant<int, 1>());
-            position(std::integral_constant<int, 3>());
+            position(std::integral_constant<int, 3>(), nothing);
             update_t(M[0], std::integral_constant<int, 2>());
-            position(std::integral_constant<int, 4>());
+            position(std::integral_constant<int, 4>(), nothing);
             update_t(M[1], std::integral_constant<int, 3>());
-            position(std::integral_constant<int, 5>());
+            position(std::integral_constant<int, 5>(), nothing);
             update_t(M[0], std::integral_constant<int, 4>());
+            }
         }
     } else {
 #pragma unroll

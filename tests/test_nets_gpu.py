@@ -650,6 +650,33 @@ def test_fused_winograd_compile_time_scheduled_loop_is_bit_identical_to_the_gene
     assert torch.equal(resnet.get_vec(xt), resnet.get_vec(xt))
 
 
+def test_conv_engine_scheduled_1x1_loop_is_bit_identical_to_modes_3_and_6(resnet, dev, monkeypatch):
+    """Round 5: 1x1 layers whose K is a whole number of 16-deep chunks run the engine's scheduled loop (KMODE 7 / 8: lane offsets constant,
+    k offset in the buffer instructions' scalar offset, ring slot a compile-time constant -- no VALU instruction left beside the MFMAs).
+    Same products in the same order as modes 3 / 6 (MM_CONV_SCHED=0 at create time): the same BITS, on the default schedule, on the direct
+    form (every layer through the engine), with the projection as its own launch (MM_FUSE_PROJ=0: residual epilogue on mode 7), and on a
+    batch whose rows do not fill the last tile; tail-split remainder launches (64x64 tiles) included via a 64-frame batch."""
+    from mimamo_net_amd.resnet50_extractor import Resnet50_Extractor
+    sd = weights.make_resnet50_state_dict(seed=0)
+    for env, n in ((None, 3), (("MM_FUSE_PROJ", "0"), 2), (None, 64)):
+        if env:
+            monkeypatch.setenv(*env)
+        xt = torch.from_numpy(_images(n, 41)).to(dev)
+        new = Resnet50_Extractor(state_dict=sd, device=dev)
+        monkeypatch.setenv("MM_CONV_SCHED", "0")
+        twin = Resnet50_Extractor(state_dict=sd, device=dev)
+        monkeypatch.delenv("MM_CONV_SCHED")
+        for mode in ((True, 0) if n < 64 else (True,)):
+            new.set_winograd(mode)
+            twin.set_winograd(mode)
+            a, b = new.get_vec(xt), twin.get_vec(xt)
+            assert torch.equal(a, b), (env, n, mode, (a - b).abs().max().item())
+        new.close()
+        twin.close()
+        if env:
+            monkeypatch.delenv(env[0])
+
+
 def test_resnet50_bf16x3_mode(resnet, oracle, dev):
     """mm_resnet50_set_precision(1) -- bench.py's extra.bf16x3, never the headline: the 1x1 layers with K >= 512 as six bf16 MFMA
     products of three-way split fp32 operands.  pool5 against the fp32 oracle and against a float64 evaluation at the CONTRACT bounds

@@ -138,6 +138,40 @@ static double run_inter(int w, int iters, float* out, float* in) {
     return ms * 1e-3 / iters;
 }
 
+// Fifth experiment: the same FMAs as packed instructions: 32 x [MFMA, F x v_pk_fma_f32] does 2 F FMAs per gap -- against 2 F x v_fma_f32.
+typedef float f32x2p __attribute__((ext_vector_type(2)));
+template <int F>
+__global__ void __launch_bounds__(256) probe32_interleaved_pk(float* out, const float* in, int iters) {
+    f32x2p y[16];
+    for (int e = 0; e < 16; ++e) y[e] = f32x2p{in[(threadIdx.x * 8 + e) & 2047], in[(threadIdx.x * 8 + e + 16) & 2047]};
+    f32x4 acc[2] = {};
+    const float a = in[threadIdx.x & 63], b = in[(threadIdx.x + 7) & 63];
+    const f32x2p c = {1.0009765625f, 1.0009765625f}, av = {a, b};
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int t = 0; t < 32; ++t) {
+            acc[t & 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[t & 1], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int v = 0; v < F; ++v) asm volatile("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(y[(t * F + v) & 15]) : "v"(c), "v"(av));
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    float s = 0.f;
+    for (int e = 0; e < 16; ++e) s += y[e][0] + y[e][1];
+    out[blockIdx.x * 256 + threadIdx.x] = s + acc[0][0] + acc[1][3];
+}
+template <int F>
+static double run_inter_pk(int w, int iters, float* out, float* in) {
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    probe32_interleaved_pk<F><<<256 * w, 256>>>(out, in, 10);
+    hipEventRecord(e0);
+    probe32_interleaved_pk<F><<<256 * w, 256>>>(out, in, iters);
+    hipEventRecord(e1); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    return ms * 1e-3 / iters;
+}
+
 template <int NV, bool MFMA>
 static double run32(int wg_per_cu, int iters, float* out, float* in) {
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
@@ -192,5 +226,10 @@ int main() {
     for (int w = 1; w <= 2; ++w)
         printf("%5d    %7.1f  %7.1f  %7.1f  %7.1f  %7.1f\n", w, run_inter<0>(w, iters, out, in) * 1e9, run_inter<2>(w, iters, out, in) * 1e9,
                run_inter<4>(w, iters, out, in) * 1e9, run_inter<6>(w, iters, out, in) * 1e9, run_inter<8>(w, iters, out, in) * 1e9);
+    printf("\nfp32, the same with PACKED fillers: 32 x [MFMA, F x v_pk_fma_f32] (2 F FMAs per gap)\n");
+    printf("waves/SIMD    F=0      F=1      F=2      F=3      F=4\n");
+    for (int w = 1; w <= 2; ++w)
+        printf("%5d    %7.1f  %7.1f  %7.1f  %7.1f  %7.1f\n", w, run_inter_pk<0>(w, iters, out, in) * 1e9, run_inter_pk<1>(w, iters, out, in) * 1e9,
+               run_inter_pk<2>(w, iters, out, in) * 1e9, run_inter_pk<3>(w, iters, out, in) * 1e9, run_inter_pk<4>(w, iters, out, in) * 1e9);
     return 0;
 }
