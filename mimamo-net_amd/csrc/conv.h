@@ -36,6 +36,9 @@ struct ConvParams {
     int sched1x1;    // set by conv_forward: 1x1 layer with K % 16 == 0 on the scheduled loop (conv_mfma.hip KMODE 7 / 8)
     int no_sched;    // 1: keep modes 3 / 6 for such a layer (the parity twin of the scheduled loop)
     int x3;          // 1: 1x1 layer on the bf16 matrix pipes through a three-way bf16 split of both fp32 operands (conv_mfma.hip X3; `extra` only)
+    int hpool;       // 1 (korder 2 -- the stem -- with Cout == 64, Wo even, out_cstride == 64 only): the epilogue writes the HORIZONTAL half of
+                     // MaxPool2d(3, 2, pad 0): out [B, Ho, Wo / 2, 64], out(b, y, j) = max over x in {2j, 2j+1, 2j+2 (if < Wo)} of relu(conv + bias)
+                     // -- half the bytes; maxpool_reduce64(..., hp = 1) finishes the pool vertically (round 5, conv_mfma.hip "hpool")
 };
 
 int conv_forward(const ConvParams& p, hipStream_t stream);
@@ -49,8 +52,9 @@ int maxpool3x3s2(const float* in, float* out, int64_t N, int H, int W, int C, in
 // the same pool AND the 1x1 conv that follows it at conv2_1 (64 -> 64, w [64][64] BN-folded, + bias, ReLU) in one kernel (pool_reduce.hip;
 // the pooled values reach the MFMA through a wave-private LDS stage):
 // x_out = the pooled tensor (bit-identical to maxpool3x3s2), y_out = relu?(w x + bias); NHWC, 64 channels
+// hp = 1: `in` is the horizontally pooled stem output [N, H, ceil(W / 2), 64] (ConvParams::hpool): three vertical taps per pixel instead of nine
 int maxpool_reduce64(const float* in, const float* w, const float* bias, float* x_out, float* y_out, int64_t N, int H, int W, int Ho, int Wo,
-                     int relu, hipStream_t s);
+                     int relu, hipStream_t s, int hp = 0);
 // global average pool over HW (AvgPool2d(k=HW side)); optional ReLU afterwards
 int avgpool_hw(const float* in, float* out, int64_t N, int HW, int C, int out_cstride, int out_coff, int relu, hipStream_t s);
 // Winograd F(m x m, 3x3) transforms around a batched GEMM (winograd.hip), m = 2 or 4, a = m + 2

@@ -103,6 +103,11 @@ constexpr int CLD = 16;   // LDS row = one 16-float chunk; the four 16-byte slot
 //      ring slot is a compile-time constant that folds into the ds_read_b128 offset fields and into the M0 immediates of the DMA.  Why:
 //      tools/probes/valu_mfma_overlap.hip -- VALU issue time ADDS to matrix time on gfx950 (22 VALU instructions per 32 MFMAs in mode 3:
 //      fragment addresses, lane offsets + their out-of-range selects).  Same products in the same order: bit-identical to modes 3 / 6.
+//   9  (round 5) mode 5 for the 7x7 stem exactly (K = 7 x 24 = 168 -> 176: eleven chunks), fully unrolled: the tap offset of a lane's k-quad in
+//      chunk c -- row (4 c + kq) / 6 of the window, quad (4 c + kq) % 6 of that row -- is not separable into a lane part and a chunk part, so the
+//      22 byte offsets (11 chunks x 2 pieces) are computed once and held in registers; ring slots, the weight rows' k offset (scalar offset)
+//      and the counted waits are compile-time constants.  Mode 5's loop spent ~28 vector instructions per 16 MFMAs on them.
+//      Rows past M read a valid row instead of zeros (their results are never stored), quads past K = 168 meet zero weights as in mode 5.
 // (the scheduled 1x1 loop of the 128x128 tile would take 188 registers -- every fragment read of a step in flight at once -- where its mode-3
 //  twin's 156 keep three workgroups on a CU: held to three waves per SIMD.  The bf16x3 instantiations are held to the occupancy of their fp32 twins: the eight-wave one needs 133 registers where 128 keep two
 //  workgroups on a CU; the four-wave 128x256 one -- 64x128 wave tiles -- 280 where 256 keep two waves on a SIMD)
@@ -149,7 +154,10 @@ conv_mfma_kernel(const ConvParams p) {
     const float* __restrict__ w_b = p.w + (int64_t)bz * p.w_bstride;
     float* __restrict__ out_b = p.out + (int64_t)bz * p.out_bstride;
     const int tile_m = logical / p.tiles_n, tile_n = logical - tile_m * p.tiles_n;
-    const int m_base = p.m_off + tile_m * BM, n_base = tile_n * BN;
+    // hpool (the stem, KMODE 5 on the 128x64 tile): tiles start every BM - 2 rows -- a tile's last two pixels are computed again by the
+    // next one, so that every 3-pixel pooling window that starts at an even pixel lies inside ONE tile (1.6 % more MFMA work)
+    const bool hpool = (KMODE == 5 || KMODE == 9) && BM == 128 && BN == 64 && p.hpool;
+    const int m_base = p.m_off + tile_m * (hpool ? BM - 2 : BM), n_base = tile_n * BN;
 
     // ---- operand fetch through buffer descriptors: the hardware range check returns 0 for any offset
     //      >= num_records, which gives zero padding (image border taps, K tail, row/channel tails) without
@@ -203,8 +211,8 @@ conv_mfma_kernel(const ConvParams p) {
     //              chunks and is served by L1/L2 instead of the fabric (measured: conv4_x 3x3 fetched 8.5x its
     //              input with korder 0).
     int tk = kq * 4, tr, ts, tc;
-    const int rgq = KMODE == 5 ? (p.kw * 3 + 3) / 4 : 1;   // k-quads per kernel row (KMODE 5)
-    if (KMODE == 5) {
+    const int rgq = (KMODE == 5 || KMODE == 9) ? (p.kw * 3 + 3) / 4 : 1;   // k-quads per kernel row (KMODE 5)
+    if (KMODE == 5 || KMODE == 9) {
         tr = kq / rgq;
         ts = kq - tr * rgq;      // quad inside the row group
         tc = 0;
@@ -410,6 +418,85 @@ conv_mfma_kernel(const ConvParams p) {
         }
         if (nk - kc >= 1) step(std::integral_constant<int, 0>());
         if (nk - kc == 2) step(std::integral_constant<int, 1>());
+    } else if constexpr (KMODE == 9) {
+        static_assert(!ABL && !X3, "the scheduled stem loop has no measurement / bf16x3 form");
+        constexpr int NK = 11;                               // 7 kernel rows x 24 floats = 168 -> 176 (conv_forward checks)
+        unsigned vat[NK][AIT];
+#pragma unroll
+        for (int c = 0; c < NK; ++c) {
+            const int g = 4 * c + kq, r = g / 6, q = g - 6 * r;
+            const int tapoff = r * p.W * 3 + q * 4;
+#pragma unroll
+            for (int it = 0; it < AIT; ++it) {
+                vat[c][it] = (unsigned)(a_pix[it] + tapoff) * 4u;      // (rows past M: a_pix is row m_base's)
+                asm volatile("" : "+v"(vat[c][it]));                    // opaque: hipcc would otherwise sink the arithmetic back into the loop
+            }
+        }
+        const unsigned wa0 = __builtin_amdgcn_readfirstlane(lds_a + (unsigned)(wave * 16 * CLD * 4));
+        const unsigned wb0 = __builtin_amdgcn_readfirstlane(lds_b + (unsigned)(wave * 16 * CLD * 4));
+        auto piece9 = [&](const __amdgpu_buffer_rsrc_t& rsrc, unsigned voff, unsigned wbase, auto lds_tag, auto k_tag) {
+            unsigned keep;
+            // (the k offset of the weight rows rides in the SCALAR offset: the instruction's offset field would also move the LDS address)
+            asm volatile("s_mov_b32 %0, m0\n\ts_add_u32 m0, %3, %4\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %5 offen lds\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep) : "v"(voff), "s"(rsrc), "s"(wbase), "n"(decltype(lds_tag)::value), "s"((unsigned)decltype(k_tag)::value) : "memory", "scc");
+        };
+        auto dma9 = [&](auto c_tag) {
+            constexpr int C_ = decltype(c_tag)::value, SLOT = C_ % NBUF;
+            static_for<AIT>([&](auto it_tag) {
+                constexpr int IT = decltype(it_tag)::value;
+                piece9(rsrc_a, vat[C_][IT], wa0, std::integral_constant<int, (SLOT * BM + IT * RPR) * CLD * 4>(), std::integral_constant<int, 0>());
+            });
+            static_for<BIT>([&](auto it_tag) {
+                constexpr int IT = decltype(it_tag)::value;
+                piece9(rsrc_b, vb[IT], wb0, std::integral_constant<int, (SLOT * BN + IT * RPR) * CLD * 4>(), std::integral_constant<int, C_ * CBK * 4>());
+            });
+        };
+        int fao[TM][2], fbo[TN][2];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int r = wm * WM + i * 32 + lr, g = (r >> 2) & 3;
+            fao[i][0] = r * CLD + (((2 * lh) ^ g) << 2);
+            fao[i][1] = r * CLD + (((2 * lh + 1) ^ g) << 2);
+        }
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int r = wn * WN + j * 32 + lr, g = (r >> 2) & 3;
+            fbo[j][0] = r * CLD + (((2 * lh) ^ g) << 2);
+            fbo[j][1] = r * CLD + (((2 * lh + 1) ^ g) << 2);
+        }
+        dma9(std::integral_constant<int, 0>());
+        dma9(std::integral_constant<int, 1>());
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" :: "n"(NL) : "memory");   // chunk 0 landed (chunk 1 still in flight)
+        static_for<NK>([&](auto kc_tag) {
+            constexpr int KC = decltype(kc_tag)::value, BUF = KC % NBUF;
+            if constexpr (KC + 2 < NK) dma9(std::integral_constant<int, KC + 2>());
+            float4 qa[TM][2], qb[TN][2];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                qa[i][0] = *reinterpret_cast<const float4*>(As + BUF * BM * CLD + fao[i][0]);
+                qa[i][1] = *reinterpret_cast<const float4*>(As + BUF * BM * CLD + fao[i][1]);
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                qb[j][0] = *reinterpret_cast<const float4*>(Bs + BUF * BN * CLD + fbo[j][0]);
+                qb[j][1] = *reinterpret_cast<const float4*>(Bs + BUF * BN * CLD + fbo[j][1]);
+            }
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int j = 0; j < TN; ++j) {
+                            const float a = kk == 0 ? qa[i][h].x : kk == 1 ? qa[i][h].y : kk == 2 ? qa[i][h].z : qa[i][h].w;
+                            const float b = kk == 0 ? qb[j][h].x : kk == 1 ? qb[j][h].y : kk == 2 ? qb[j][h].z : qb[j][h].w;
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[i][j], 0, 0, 0);
+                        }
+            // chunk KC + 1 landed (chunk KC + 2, when there is one, may still be in flight); the last chunk is followed by the drain below
+            if constexpr (KC + 1 < NK)
+                asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" :: "n"(KC + 2 < NK ? NL : 0) : "memory");
+        });
     } else {
     tap_offsets();
     dma(0);
@@ -522,6 +609,44 @@ conv_mfma_kernel(const ConvParams p) {
     }
     }
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");   // drain the over-issued loads before LDS is re-used
+
+    // ---- hpool epilogue (round 5): the stem's output is only ever read by MaxPool2d(3, 2, pad 0) -- 6.6 GB written and 10 GB read back
+    // per 2 048 frames.  The pool's HORIZONTAL half runs here: the whole 128 x 64 tile goes through LDS as relu(acc + bias), then a thread
+    // takes the maximum over pixels (m, m + 1, m + 2) of one channel quad for the even m of the tile (m + 2 only while it is in the same
+    // image row: the ceil-mode window at the right border has two columns) and writes pooled pixel m / 2 -- [B, Ho, Wo / 2, 64], half the
+    // bytes, and the kernel that finishes the pool (pool_reduce.hip, hp = 1) reads three rows per pixel instead of nine pixels.
+    // max is exact and order-free: the pooled tensor is bit-identical to pooling the full stem output.
+    if constexpr ((KMODE == 5 || KMODE == 9) && BM == 128 && BN == 64) {
+        if (hpool) {
+            static_assert(TN == 1 && WN == 32, "one 32-channel accumulator column per wave");
+            constexpr int TLD = BN + 4;                          // row stride of the staged tile (floats): 16-byte aligned rows, odd in 16-byte units
+            static_assert(BM * TLD <= OPER_FLOATS, "the staged tile fits the dead operand ring");
+            float* T = lds;
+            const float bias = p.bias ? p.bias[wn * WN + lr] : 0.f;
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const float v = acc[i][0][e] + bias;
+                    T[(wm * WM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh) * TLD + wn * WN + lr] = p.relu ? fmaxf(v, 0.f) : v;
+                }
+            __syncthreads();
+            typedef float f32x4_t __attribute__((ext_vector_type(4)));
+#pragma unroll
+            for (int idx = tid; idx < (BM / 2 - 1) * (BN / 4); idx += NW * 64) {
+                const int u = idx / (BN / 4), q = idx - u * (BN / 4);
+                const int m = m_base + 2 * u;
+                if (m >= p.M) continue;                          // (M is even: m + 1 < M as well)
+                const float4 a = *reinterpret_cast<const float4*>(T + (2 * u) * TLD + 4 * q);
+                const float4 b = *reinterpret_cast<const float4*>(T + (2 * u + 1) * TLD + 4 * q);
+                const float4 c = *reinterpret_cast<const float4*>(T + (2 * u + 2) * TLD + 4 * q);
+                f32x4_t o = {fmaxf(a.x, b.x), fmaxf(a.y, b.y), fmaxf(a.z, b.z), fmaxf(a.w, b.w)};
+                if (m % p.Wo != p.Wo - 2) o = f32x4_t{fmaxf(o[0], c.x), fmaxf(o[1], c.y), fmaxf(o[2], c.z), fmaxf(o[3], c.w)};
+                __builtin_nontemporal_store(o, reinterpret_cast<f32x4_t*>(out_b + (int64_t)(m >> 1) * BN + 4 * q));
+            }
+            return;
+        }
+    }
 
     // ---- fused epilogue.  MFMA C layout: col = lane & 31, row = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5), i.e. a
     // lane owns a 16-row strip of ONE channel.  Per-lane stores of that layout are 4-byte, row-strided and
@@ -651,6 +776,7 @@ static int num_cus() {
 template <int BM, int BN, int WGM, int WGN, int KMODE, bool ABL = false, bool X3 = false>
 static int launch_km(ConvParams p, hipStream_t stream) {
     p.tiles_m = (p.M - p.m_off + BM - 1) / BM;
+    if (p.hpool) p.tiles_m = (p.M / 2 + (BM / 2 - 1) - 1) / (BM / 2 - 1);     // BM / 2 - 1 pooled pixels per tile (tiles overlap by two rows)
     p.tiles_n = (p.Cout + BN - 1) / BN;
     if (p.batch < 1) p.batch = 1;
     const int64_t blocks = (int64_t)p.tiles_m * p.tiles_n * p.batch;
@@ -668,7 +794,13 @@ static int launch_km(ConvParams p, hipStream_t stream) {
 
 template <int BM, int BN, int WGM, int WGN>
 static int launch_cfg(const ConvParams& p, hipStream_t stream) {
-    if (p.korder == 2) return launch_km<BM, BN, WGM, WGN, 5>(p, stream);
+    if (p.korder == 2) {
+        // the 7x7 stem (eleven chunks) takes the fully unrolled loop unless the caller asks for the twin (no_sched)
+        if constexpr (BN == 64) {
+            if (!p.no_sched && p.kh == 7 && p.kw == 7 && p.Kpad == 176 && p.force_tile < 16) return launch_km<BM, BN, WGM, WGN, 9>(p, stream);
+        }
+        return launch_km<BM, BN, WGM, WGN, 5>(p, stream);
+    }
     if constexpr (BN >= 64 && BM != 256) {      // the bf16x3 instantiations exist for the 1x1 forms on the 64x64 / 128x128 tiles (and 128x256 below)
         if (p.x3 && p.in2) return launch_km<BM, BN, WGM, WGN, 6, false, true>(p, stream);
         if (p.x3 && p.kh == 1 && p.kw == 1 && p.pad == 0) return launch_km<BM, BN, WGM, WGN, 3, false, true>(p, stream);
@@ -711,6 +843,12 @@ int conv_forward(const ConvParams& p0, hipStream_t stream) {
         if (span * p.H2 * p.W2 * p.in2_cstride * 4 >= 0x7FFFF000ll) return MM_ERR_INVALID_ARG;
     }
     if (p.x3 && !(p.kh == 1 && p.kw == 1 && p.pad == 0 && p.korder == 0)) p.x3 = 0;   // bf16x3 exists for the 1x1 forms only
+    if (p.hpool) {   // horizontally pooled output: the stem form on the 128x64 tile only (the tile is the whole channel range)
+        if (p.korder != 2 || p.Cout != 64 || p.out_cstride != 64 || p.out_coff != 0 || p.Wo % 2 || p.Wo < 4 || p.res || p.post_scale || p.batch > 1 ||
+            p.m_off != 0 || p.m_end != 0 || (p.force_tile != 0 && p.force_tile != 2))
+            return MM_ERR_INVALID_ARG;
+        p.force_tile = 2;
+    }
     // 1x1 layers whose K is a whole number of chunks take the scheduled loop (KMODE 7 / 8) unless the caller asks for modes 3 / 6 (no_sched:
     // MM_CONV_SCHED=0 at mm_resnet50_create, the parity twin)
 #ifndef MM_SCHED_RES_MINK

@@ -182,7 +182,7 @@ constexpr int kX3MinK = 512;   // mm_resnet50_set_precision(h, 1): 1x1 layers wi
 
 static int run_layer(const Layer& L, const float* in, int B, int H, int W, int in_cstride, int in_coff, float* out,
                      int out_cstride, int out_coff, const float* res, int res_cstride, hipStream_t s, int* Ho_ = nullptr,
-                     int* Wo_ = nullptr, int x3 = 0, int no_sched = 0) {
+                     int* Wo_ = nullptr, int x3 = 0, int no_sched = 0, int hpool = 0) {
     ConvParams p;
     std::memset(&p, 0, sizeof(p));
     p.in = in; p.w = L.w; p.bias = L.bias; p.res = res; p.post_scale = L.ps; p.post_shift = L.pt; p.out = out;
@@ -195,6 +195,7 @@ static int run_layer(const Layer& L, const float* in, int B, int H, int W, int i
     p.K = L.K; p.Kpad = L.Kpad; p.relu = L.relu; p.Cin_real = L.cin; p.korder = L.korder; p.force_tile = L.tile;
     p.x3 = x3 && L.k == 1 && L.Kpad >= kX3MinK;
     p.no_sched = no_sched;
+    p.hpool = hpool;
     if (Ho_) *Ho_ = p.Ho;
     if (Wo_) *Wo_ = p.Wo;
     return conv_forward(p, s);
@@ -301,7 +302,9 @@ struct mm_resnet50 {
     int ceil_mode;
     int winograd;  // 0 direct, 2 = F(2x2,3x3), 4 = F(4x4,3x3) for the layers that have Winograd-domain weights
     int fuse_proj; // 1 (default): the first block of a stage runs increase + projection as one launch
-    int fuse_pool; // 1 (default): pool1 and conv2_1's 1x1 reduce conv run as one kernel (pool_reduce.hip)
+    int fuse_pool; // pool1 and conv2_1's 1x1 reduce conv run as one kernel (pool_reduce.hip): 0 = two launches (the parity twin), 1 = one kernel over
+                   // the full stem output, 2 (default) = the packed-NHWC3 stem also pools horizontally in its epilogue (conv_mfma.hip hpool) and the
+                   // pool kernel finishes vertically -- the 112 x 112 x 64 stem output never exists
     int no_sched;  // MM_CONV_SCHED=0 at create time: 1x1 layers on the engine's modes 3 / 6 instead of the scheduled loop (modes 7 / 8): the parity twin
     int wf_generic;// MM_WF_KSL=0 at create time: the fused Winograd kernels' runtime-scheduled main loop (the parity twin of round 5's compile-time one)
     int precision; // 0 (default): every contraction on the fp32 matrix pipes; 1: 1x1 layers with K >= 512 through the three-way bf16 split
@@ -430,8 +433,8 @@ int mm_resnet50_create(mm_resnet50_t** out, const float* blob, int64_t n_floats,
         h->no_sched = cs ? atoi(cs) == 0 : 0;
         const char* fp = getenv("MM_FUSE_PROJ");   // measurement knob: 0 = projection shortcut as its own launch + residual read
         h->fuse_proj = fp ? atoi(fp) : 1;
-        const char* fpl = getenv("MM_FUSE_POOL");  // measurement knob: 0 = max-pool and conv2_1's reduce conv as two launches (the parity twin)
-        h->fuse_pool = fpl ? atoi(fpl) : 1;
+        const char* fpl = getenv("MM_FUSE_POOL");  // measurement knob: 0 = max-pool and conv2_1's reduce conv as two launches (the parity twin),
+        h->fuse_pool = fpl ? atoi(fpl) : 2;        // 1 = one kernel on the full stem output, 2 = horizontal half of the pool in the stem's epilogue
         const char* fi = getenv("MM_FUSE_INC");    // measurement knob: 0 = 3x3 and increase conv as separate launches (the parity twin)
         // 1 = conv2_x blocks 2, 3 only; 2 = also block 1 (increase | projection over two K sources); 3 = also conv3_x blocks 2-4
         h->fuse_inc = fi ? atoi(fi) : 3;
@@ -541,6 +544,12 @@ int mm_resnet50_forward(mm_resnet50_t* h, const float* images, int nchw, int64_t
     int rc;
     const float* x0 = images;
     int H = 224, W = 224, Ho, Wo;
+    // pool1 + conv2_1_1x1_reduce in one kernel when that block starts with a stride-1 64 -> 64 1x1 conv (the published graph); with the
+    // packed three-channel stem (fuse_pool 2) the stem's epilogue does the horizontal half of the pool
+    const mm::Layer& R0 = h->blocks.front().reduce;
+    const bool pooled_reduce = h->fuse_pool && R0.k == 1 && R0.stride == 1 && R0.pad == 0 && R0.cin_p == 64 && R0.cout == 64 && R0.Kpad == 64 &&
+                               R0.korder == 0 && !R0.ps;
+    const bool hpool = pooled_reduce && h->fuse_pool >= 2 && nchw;
     if (nchw) {
         // zero-bordered packed NHWC3 [batch, 230, 230, 3]: handed over (2, mm_preproc_forward layout 2) or converted from the
         // reference's NCHW (1) into the workspace (230 * 230 * 3 < 224 * 224 * 4 floats); stem with K = 168
@@ -549,7 +558,7 @@ int mm_resnet50_forward(mm_resnet50_t* h, const float* images, int nchw, int64_t
             if (rc != MM_OK) return rc;
             x0 = in4;
         }
-        rc = run_layer(h->stem3, x0, B, 230, 230, 3, 0, big[0], 64, 0, nullptr, 0, s, &Ho, &Wo);
+        rc = run_layer(h->stem3, x0, B, 230, 230, 3, 0, big[0], 64, 0, nullptr, 0, s, &Ho, &Wo, 0, h->no_sched, hpool);
     } else {
         rc = run_layer(h->stem, x0, B, H, W, 4, 0, big[0], 64, 0, nullptr, 0, s, &Ho, &Wo);   // NHWC4: K = 196
     }
@@ -564,17 +573,10 @@ int mm_resnet50_forward(mm_resnet50_t* h, const float* images, int nchw, int64_t
     } else {
         Ho = (H - 3) / 2 + 1; Wo = (W - 3) / 2 + 1;
     }
-    // pool1 + conv2_1_1x1_reduce in one kernel when that block starts with a stride-1 64 -> 64 1x1 conv (the published graph)
-    bool pooled_reduce = false;
-    {
-        const Layer& R = h->blocks.front().reduce;
-        if (h->fuse_pool && R.k == 1 && R.stride == 1 && R.pad == 0 && R.cin_p == 64 && R.cout == 64 && R.Kpad == 64 && R.korder == 0 && !R.ps) {
-            rc = maxpool_reduce64(big[0], R.w, R.bias, big[1], y1, batch, H, W, Ho, Wo, R.relu, s);
-            pooled_reduce = true;
-        } else {
-            rc = maxpool3x3s2(big[0], big[1], batch, H, W, 64, Ho, Wo, s);
-        }
-    }
+    if (pooled_reduce)
+        rc = maxpool_reduce64(big[0], R0.w, R0.bias, big[1], y1, batch, H, W, Ho, Wo, R0.relu, s, hpool);
+    else
+        rc = maxpool3x3s2(big[0], big[1], batch, H, W, 64, Ho, Wo, s);
     if (rc != MM_OK) return rc;
     H = Ho; W = Wo;
     int xi = 1;  // index of the buffer holding the block input

@@ -25,6 +25,11 @@ typedef float f32x4p __attribute__((ext_vector_type(4)));
 //   3. transposes relu(y + bias) through the stage so that the stores are 256 contiguous bytes per pixel again.
 // A wave's LDS operations execute in issue order and the stage is wave-private: no workgroup barrier after the matrix load.
 constexpr int PR_WAVES = 4, PR_GPW = 8;     // waves per workgroup, pixel groups per wave (measured 8 / 16 / 32 / 64: 1.82 / 1.84 / 1.91 / 2.04 ms per 2 048 frames)
+// HP (round 5): `in` is the stem output already pooled HORIZONTALLY by the stem's own epilogue (conv_mfma.hip hpool: [N, H, WP, 64] with
+// WP = W / 2 columns, column j = max over x in {2j, 2j+1, 2j+2}): a pixel takes three vertical taps of ITS column instead of nine pixels --
+// a third of the load instructions, and 4.9 instead of 10.1 GB read per 2 048 frames (PMC: every input row but the even ones is shared by
+// two output rows that different workgroups pool at different times; with nine taps that re-read hit HBM at full width).
+template <bool HP>
 __global__ void __launch_bounds__(PR_WAVES * 64)
 maxpool_reduce64_kernel(const float* __restrict__ in, const float* __restrict__ w, const float* __restrict__ bias, float* __restrict__ x_out,
                         float* __restrict__ y_out, int64_t M, int H, int W, int Ho, int Wo, int relu, int64_t groups) {
@@ -59,6 +64,19 @@ maxpool_reduce64_kernel(const float* __restrict__ in, const float* __restrict__ 
             f32x4p v = {-3.4e38f, -3.4e38f, -3.4e38f, -3.4e38f};
             // ceil-mode windows are clipped at the border: a tap past it re-reads the last row / column of the window, which leaves
             // the maximum unchanged -- no branches, the nine loads of a round (36 per group) are issued as one batch
+            if constexpr (HP) {
+                f32x4p a[3];
+                const int WP = W >> 1;
+#pragma unroll
+                for (int r = 0; r < 3; ++r) {
+                    const int hi = min(ho * 2 + r, H - 1);
+                    a[r] = *reinterpret_cast<const f32x4p*>(in + ((n * H + hi) * WP + wo) * C + 4 * c4);
+                }
+#pragma unroll
+                for (int k = 0; k < 3; ++k)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], a[k][e]);
+            } else {
             f32x4p a[9];
 #pragma unroll
             for (int r = 0; r < 3; ++r) {
@@ -73,6 +91,7 @@ maxpool_reduce64_kernel(const float* __restrict__ in, const float* __restrict__ 
             for (int k = 0; k < 9; ++k)
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], a[k][e]);
+            }
             if (ok) __builtin_nontemporal_store(v, reinterpret_cast<f32x4p*>(x_out + m * C + 4 * c4));
             *reinterpret_cast<f32x4p*>(stage + pl * C + ((c4 ^ pl) << 2)) = v;
         }
@@ -120,8 +139,9 @@ maxpool_reduce64_kernel(const float* __restrict__ in, const float* __restrict__ 
 
 // in NHWC [N,H,W,64] -> x NHWC [N,Ho,Wo,64] = MaxPool2d(3, 2, 0, ceil_mode as given by Ho / Wo), y = relu?(w x + bias), w [64][64]
 int maxpool_reduce64(const float* in, const float* w, const float* bias, float* x_out, float* y_out, int64_t N, int H, int W, int Ho, int Wo,
-                     int relu, hipStream_t s) {
+                     int relu, hipStream_t s, int hp) {
     if (!in || !w || !x_out || !y_out || N < 0 || H <= 0 || W <= 0 || Ho <= 0 || Wo <= 0) return MM_ERR_INVALID_ARG;
+    if (hp && (W % 2 || Wo > W / 2)) return MM_ERR_INVALID_ARG;
     const int64_t M = N * Ho * Wo;
     if (M <= 0) return MM_OK;
     const int64_t groups = (M + 15) / 16;
@@ -130,8 +150,12 @@ int maxpool_reduce64(const float* in, const float* w, const float* bias, float* 
     int64_t blocks = (groups + PR_WAVES * PR_GPW - 1) / (PR_WAVES * PR_GPW);
     if (blocks < 1) blocks = 1;
     if (blocks > 0x7fffffff) return MM_ERR_INVALID_ARG;
-    prof_before(4, (double)N * 64 * 4.0 * ((double)H * W + 2.0 * Ho * Wo), s, "maxpool+reduce64");   // stem output read once, x and y1 written
-    hipLaunchKernelGGL(maxpool_reduce64_kernel, dim3((unsigned)blocks), dim3(PR_WAVES * 64), 0, s, in, w, bias, x_out, y_out, M, H, W, Ho, Wo, relu, groups);
+    // algorithmic bytes: the (horizontally pooled) stem output read once, x and y1 written
+    prof_before(4, (double)N * 64 * 4.0 * ((double)H * (hp ? W / 2 : W) + 2.0 * Ho * Wo), s, hp ? "vpool+reduce64" : "maxpool+reduce64");
+    if (hp)
+        hipLaunchKernelGGL(maxpool_reduce64_kernel<true>, dim3((unsigned)blocks), dim3(PR_WAVES * 64), 0, s, in, w, bias, x_out, y_out, M, H, W, Ho, Wo, relu, groups);
+    else
+        hipLaunchKernelGGL(maxpool_reduce64_kernel<false>, dim3((unsigned)blocks), dim3(PR_WAVES * 64), 0, s, in, w, bias, x_out, y_out, M, H, W, Ho, Wo, relu, groups);
     prof_after(4, s);
     MM_LAUNCH_CHECK();
     return MM_OK;

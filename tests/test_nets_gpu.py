@@ -655,7 +655,9 @@ def test_conv_engine_scheduled_1x1_loop_is_bit_identical_to_modes_3_and_6(resnet
     k offset in the buffer instructions' scalar offset, ring slot a compile-time constant -- no VALU instruction left beside the MFMAs).
     Same products in the same order as modes 3 / 6 (MM_CONV_SCHED=0 at create time): the same BITS, on the default schedule, on the direct
     form (every layer through the engine), with the projection as its own launch (MM_FUSE_PROJ=0: residual epilogue on mode 7), and on a
-    batch whose rows do not fill the last tile; tail-split remainder launches (64x64 tiles) included via a 64-frame batch."""
+    batch whose rows do not fill the last tile; tail-split remainder launches (64x64 tiles) included via a 64-frame batch.  The same knob
+    switches the packed-NHWC3 stem between its fully unrolled eleven-chunk loop (KMODE 9: 22 precomputed tap offsets, no vector instruction
+    in the loop) and mode 5 -- with the pooling epilogue (MM_FUSE_POOL=2, default) on both."""
     from mimamo_net_amd.resnet50_extractor import Resnet50_Extractor
     sd = weights.make_resnet50_state_dict(seed=0)
     for env, n in ((None, 3), (("MM_FUSE_PROJ", "0"), 2), (None, 64)):
@@ -909,6 +911,43 @@ def test_resnet50_maxpool_and_reduce_conv_in_one_kernel(resnet, oracle, dev, mon
         resnet.set_winograd(True)
     one = resnet.get_vec(xt[2:3].contiguous())       # 196 groups of 16: another grid, same rows
     assert (one - resnet.get_vec(xt)[2:3]).abs().max().item() / scale < 1e-5
+
+
+def test_resnet50_stem_pools_horizontally_in_its_epilogue_bit_identical(resnet, dev, monkeypatch):
+    """MM_FUSE_POOL=2 (default): the packed-NHWC3 stem writes max over pixels (2j, 2j+1, 2j+2) of relu(conv + bias) -- tiles overlapping by
+    two pixels so that every window lies in one tile, the ceil-mode window at the right border clipped to two columns -- and
+    pool_reduce.hip finishes MaxPool2d(3, 2, 0) with three vertical taps (conv_mfma.hip hpool; the 112 x 112 x 64 stem output is never
+    written).  max is exact and order-free, bias / ReLU are monotone: bit-identical to MM_FUSE_POOL=1 (nine taps on the full stem output),
+    for ragged last tiles (batch 1: 6 272 pooled pixels = 99.6 tiles of 63; batch 3), in ceil and in floor mode."""
+    from mimamo_net_amd.resnet50_extractor import Resnet50_Extractor
+    sd = weights.make_resnet50_state_dict(seed=0)
+    monkeypatch.setenv("MM_FUSE_POOL", "1")
+    full = Resnet50_Extractor(state_dict=sd, device=dev)
+    full_floor = Resnet50_Extractor(state_dict=sd, device=dev, ceil_mode=False)
+    monkeypatch.delenv("MM_FUSE_POOL")
+    hp_floor = Resnet50_Extractor(state_dict=sd, device=dev, ceil_mode=False)
+    xt = torch.from_numpy(_images(3, 23)).to(dev)
+    # the knob really switches the kernels: the pool kernel's algorithmic bytes (measurement hook, category 4) drop by the half stem output
+    from mimamo_net_amd import _lib
+    L = _lib.lib()
+
+    def other_bytes(net):
+        ms, work, n = (ctypes.c_double * 5)(), (ctypes.c_double * 5)(), (ctypes.c_int64 * 5)()
+        assert L.mm_profile_begin() == 0
+        net.get_vec(xt)
+        assert L.mm_profile_end(ms, work, n) == 0
+        return work[4]
+    assert other_bytes(full) - other_bytes(resnet) == 3 * 64 * 4 * 112 * 56
+    for n in (3, 1):
+        x = xt[:n].contiguous()
+        assert torch.equal(resnet.get_vec(x), full.get_vec(x)), n
+        assert torch.equal(hp_floor.get_vec(x), full_floor.get_vec(x)), n
+    assert not torch.equal(resnet.get_vec(xt), hp_floor.get_vec(xt))        # ceil and floor mode really differ
+    try:
+        resnet.set_winograd(0); full.set_winograd(0)
+        assert torch.equal(resnet.get_vec(xt), full.get_vec(xt))
+    finally:
+        resnet.set_winograd(True)
 
 
 def test_phasenet_winograd_layers_vs_direct_form(head, oracle, dev, monkeypatch):
