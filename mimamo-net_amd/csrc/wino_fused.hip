@@ -303,13 +303,28 @@ wino_fused_kernel(const WinoFusedParams p) {
         constexpr int NSL = 6 * KSL;                         // slabs per column q
         typedef __attribute__((address_space(3))) const f32x4v* lds_f4;      // (ext-vector type: HIP's float4 struct has no address-space-3 assignment on the host pass)
         // LDS byte addresses of the fragment rows in ring slot 0; slot s adds s * SLAB_BYTES as an instruction offset
-        unsigned ab[4], bb0[4], bb1[4];
+        // (eight-wave shapes: 40 KB slabs put ring slot 2 at byte 81 920, beyond the 16-bit offset field -- hipcc would add the slot base per read
+        //  again and, no longer seeing the 16-byte alignment, split every ds_read_b128 into two ds_read2_b32.  Slot 2 gets its own base registers.)
+        constexpr bool FAR2 = (NBUF - 1) * SLAB_BYTES > 65535;
+        unsigned ab[4], bb0[4], bb1[4], ab2[4], bb0_2[4], bb1_2[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             ab[j] = lds0 + (unsigned)fa[j] * 4u;
             bb0[j] = lds0 + (unsigned)fb0[j] * 4u;
             bb1[j] = lds0 + (unsigned)fb1[j] * 4u;
+            if constexpr (FAR2) {
+                ab2[j] = ab[j] + (NBUF - 1) * SLAB_BYTES;
+                bb0_2[j] = bb0[j] + (NBUF - 1) * SLAB_BYTES;
+                bb1_2[j] = bb1[j] + (NBUF - 1) * SLAB_BYTES;
+                asm volatile("" : "+v"(ab2[j]), "+v"(bb0_2[j]), "+v"(bb1_2[j]));      // opaque: kept in registers, not re-derived per read
+            }
         }
+        // fragment row j of ring slot BUF: base register + slot offset in the instruction (slot 2 of the 40 KB slabs: its own base)
+        auto frag = [&](const unsigned (&lo)[4], const unsigned (&hi)[4], int j, auto buf_tag) -> f32x4v {
+            constexpr int BUF = decltype(buf_tag)::value;
+            if constexpr (FAR2 && BUF == NBUF - 1) return *(lds_f4)(uintptr_t)(hi[j]);
+            else return *(lds_f4)(uintptr_t)(lo[j] + BUF * SLAB_BYTES);
+        };
         const unsigned dbase = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)wave * 1024u);   // this wave's first piece in slot 0
         int dq = 0;                                           // columns the DMA stream has finished
         // DMA of the slab that is D slabs into the current column (D may run past the column's end: the stream is NBUF - 1 ahead)
@@ -395,9 +410,9 @@ wino_fused_kernel(const WinoFusedParams p) {
                     f32x4v a[2], b0[2], b1[2];
 #pragma unroll
                     for (int j = 0; j < 2; ++j) {
-                        a[j] = *(lds_f4)(uintptr_t)(ab[2 * hh + j] + BUF * SLAB_BYTES);
-                        b0[j] = *(lds_f4)(uintptr_t)(bb0[2 * hh + j] + BUF * SLAB_BYTES);
-                        b1[j] = *(lds_f4)(uintptr_t)(bb1[2 * hh + j] + BUF * SLAB_BYTES);
+                        a[j] = frag(ab, ab2, 2 * hh + j, std::integral_constant<int, BUF>());
+                        b0[j] = frag(bb0, bb0_2, 2 * hh + j, std::integral_constant<int, BUF>());
+                        b1[j] = frag(bb1, bb1_2, 2 * hh + j, std::integral_constant<int, BUF>());
                     }
                     // (no hook here: the INC kernels measured 0.5-1 % slower with the transform block pinned, r05_ab_wino_loop.txt)
 #pragma unroll
@@ -417,9 +432,9 @@ wino_fused_kernel(const WinoFusedParams p) {
             f32x4v a[4], b0[4], b1[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                a[j] = *(lds_f4)(uintptr_t)(ab[j] + BUF * SLAB_BYTES);
-                b0[j] = *(lds_f4)(uintptr_t)(bb0[j] + BUF * SLAB_BYTES);
-                b1[j] = *(lds_f4)(uintptr_t)(bb1[j] + BUF * SLAB_BYTES);
+                a[j] = frag(ab, ab2, j, std::integral_constant<int, BUF>());
+                b0[j] = frag(bb0, bb0_2, j, std::integral_constant<int, BUF>());
+                b1[j] = frag(bb1, bb1_2, j, std::integral_constant<int, BUF>());
             }
             if (MM_WF_HOOK) {
                 __builtin_amdgcn_sched_barrier(0);
@@ -1041,8 +1056,10 @@ static int launch_fused_k(WinoFusedParams p, hipStream_t s) {
 // every K when the caller asks for the twin (p.generic_loop: MM_WF_KSL=0 at create time, the parity twin) -- the generic one
 template <int NBUF, int WGM, int INC = 0, int WGN = 2>
 static int launch_fused(const WinoFusedParams& p, hipStream_t s) {
-    // (not the eight-wave shapes: their 40 KB slabs put ring slot 2 beyond the 16-bit ds_read offset, hipcc then adds the slot base per
-    //  read again -- and, no longer seeing the 16-byte alignment, splits every ds_read_b128 into two ds_read2_b32)
+    // (the eight-wave conv3_x kernel -- 2 x 4 waves, K = 128 -- takes it with a second set of fragment base registers for ring slot 2, see FAR2)
+    if constexpr (NBUF == 3 && WGM == 2 && WGN == 4 && INC == 3) {
+        if (!p.generic_loop && p.K == 128) return launch_fused_k<NBUF, WGM, INC, WGN, 2>(p, s);
+    }
     if constexpr (NBUF == 3 && WGM * WGN == 4) {
         if (!p.generic_loop && p.K == 64) return launch_fused_k<NBUF, WGM, INC, WGN, 1>(p, s);
         if constexpr (INC == 0) {      // the INC kernels exist for K = 64 only
