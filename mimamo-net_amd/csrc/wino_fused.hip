@@ -49,7 +49,9 @@ struct WinoFusedParams {
     int C2;              // 256
     int generic_loop;    // 1: the runtime-scheduled main loop whatever K is (the parity twin of the compile-time-scheduled one)
     int ablate;          // -DMM_MEASURE builds only (results wrong by construction): bit 0 = every workgroup reads the V rows of the first
-                         // 1 024 tiles (L2-resident: the kernel without its V traffic), bit 1 = residual rows from the first 4 096 pixels
+                         // 1 024 tiles (L2-resident: the kernel without its V traffic), bit 1 = residual rows from the first 4 096 pixels,
+                         // 4 = no output-transform updates in the main loop, 8 = INC 1 epilogue without residual loads, 16 = without output
+                         // stores, 32 = without its exchange barriers, 64 = without its MFMAs, 128 = main loop without the operand DMA
 };
 
 #ifndef MM_INC3_PAIR
@@ -336,6 +338,11 @@ wino_fused_kernel(const WinoFusedParams p) {
             const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(pu), 0, rec_b, 0x00020000);
             const unsigned ko = __builtin_amdgcn_readfirstlane(DKS * KS * 4);       // scalar offset of the buffer instruction
             unsigned keep;
+#ifdef MM_MEASURE
+            if (p.ablate & 128) {   // measurement only: the pieces are requested with zero records (no memory traffic, same instruction stream)
+                rec_a = rec_b = 0;
+            }
+#endif
             if constexpr (NIA == 2 && NIB == 4) {
                 asm volatile("s_mov_b32 %0, m0\n\t"
                              "s_add_u32 m0, %9, %10\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %7, %16 offen lds\n\t"
@@ -493,6 +500,18 @@ wino_fused_kernel(const WinoFusedParams p) {
             position(std::integral_constant<int, 4>(), [&]() { update_t(M[1], std::integral_constant<int, 3>()); });
             position(std::integral_constant<int, 5>(), [&]() { update_t(M[0], std::integral_constant<int, 4>()); });
             } else {
+#ifdef MM_MEASURE
+            if (p.ablate & 4) {      // measurement only: the column without its transform updates
+                position(std::integral_constant<int, 0>(), nothing);
+                position(std::integral_constant<int, 1>(), nothing);
+                position(std::integral_constant<int, 2>(), nothing);
+                position(std::integral_constant<int, 3>(), nothing);
+                position(std::integral_constant<int, 4>(), nothing);
+                position(std::integral_constant<int, 5>(), nothing);
+                Y[0][0][0] += M[0][0] + M[1][0]; Y[0][0][1] += M[0][1] + M[1][1];      // (keeps the MFMAs alive)
+                continue;
+            }
+#endif
             position(std::integral_constant<int, 0>(), nothing);
             update_t(M[1], std::integral_constant<int, 5>());   // last row of the previous column (q = 0: zeros)
             update_y(q == 0 ? 0 : q - 1);
@@ -900,7 +919,30 @@ wino_fused_kernel(const WinoFusedParams p) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) r[j] = *reinterpret_cast<const f32x4v*>(rp + h * 64 + j * 16);
         };
-        f32x4v rs[2][4], Pr[2];
+        // (round 5) the residual rows of up to MM_INC1_RES_DEPTH steps ahead are in flight: the kernel's time is the SUM of its MFMA time and
+        // its memory time (profiles/r05_inc1_ablation.txt: without residual loads / stores / operand DMA -1.0 / -1.5 / -1.1 ms of 7.8, without 64 %
+        // of the MFMAs -0.65) -- eight waves per CU with one step (4 KB per wave) of loads in flight do not cover the HBM latency.  The depth
+        // grows as the Y registers of finished positions die (8 per position): 1 for positions 0-1, 2 for 2-3, 3 from position 4 on.
+#ifndef MM_INC1_RES_DEPTH
+#define MM_INC1_RES_DEPTH 3
+#endif
+        auto res_ahead = [](int step) {      // last step whose residual rows have been requested once step `step` has issued its loads
+            if (step < 0) return 0;
+            int d = 1 + (step >> 2);
+            d = d > MM_INC1_RES_DEPTH ? MM_INC1_RES_DEPTH : d;
+            const int t = step + d;
+            return t > 31 ? 31 : t;
+        };
+        f32x4v rs[4][4], Pr[2];
+#ifdef MM_MEASURE
+        const int abl = p.ablate;
+#else
+        constexpr int abl = 0;
+#endif
+        if (abl & 8) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) rs[0][j] = rs[1][j] = rs[2][j] = rs[3][j] = f32x4v{0.f, 0.f, 0.f, 0.f};
+        } else
         res_rows(rs[0], 0);
 #pragma unroll
         for (int step = 0; step < 32; ++step) {
@@ -913,17 +955,21 @@ wino_fused_kernel(const WinoFusedParams p) {
                         const float v = Y[pp][qq][cb][e] + b1[cb][e];
                         Y[pp][qq][cb][e] = p.relu ? fmaxf(v, 0.f) : v;
                     }
-                if (step) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // the previous position's copies have been read
+                if (step && !(abl & 32)) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // the previous position's copies have been read
 #pragma unroll
                 for (int cb = 0; cb < 2; ++cb) *reinterpret_cast<f32x4v*>(xb + x_own + cb * 256) = Y[pp][qq][cb];
-                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                if (!(abl & 32)) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 #pragma unroll
                 for (int cb = 0; cb < 2; ++cb) Pr[cb] = *reinterpret_cast<const f32x4v*>(xb + x_par + cb * 256);
             }
-            if (step + 1 < 32) res_rows(rs[(step + 1) & 1], step + 1);
+            if (!(abl & 8)) {
+#pragma unroll
+                for (int t = res_ahead(step - 1) + 1; t <= res_ahead(step); ++t) res_rows(rs[t & 3], t);
+            }
             f32x4v acc[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) acc[j] = *reinterpret_cast<const f32x4v*>(b2s + c0 + h * 64 + j * 16);
+            if (!(abl & 64))
 #pragma unroll
             for (int sidx = 0; sidx < 4; ++sidx) {
                 const f32x4v Bv = sidx < 2 ? Y[pp][qq][sidx & 1] : Pr[sidx & 1];
@@ -941,11 +987,11 @@ wino_fused_kernel(const WinoFusedParams p) {
             }
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                acc[j] = acc[j] + rs[step & 1][j];
+                acc[j] = acc[j] + rs[step & 3][j];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) acc[j][e] = fmaxf(acc[j][e], 0.f);
             }
-            if (tok && 4 * ty + pp < p.H && 4 * tx + qq < p.W) {
+            if (tok && 4 * ty + pp < p.H && 4 * tx + qq < p.W && !(abl & 16)) {
                 float* op = obase + ((int64_t)pp * p.W + qq) * p.C2 + h * 64;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) __builtin_nontemporal_store(acc[j], reinterpret_cast<f32x4v*>(op + j * 16));
