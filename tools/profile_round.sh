@@ -14,4 +14,6 @@ bash $R/tools/pmc_traffic.sh 32 > $O/r05_pmc_traffic.log 2>&1
 bash $R/tools/pmc_kernel.sh conv_mfma_kernel 32 1 > $O/r05_conv_mfma_util_32clips.txt 2>&1
 bash $R/tools/pmc_kernel.sh wino_fused_kernel 32 1 >> $O/r05_conv_mfma_util_32clips.txt 2>&1
 bash $R/tools/layer_roofline.sh 32 > $O/r05_layer_roofline.log 2>&1      # -> r05_layer_table_32clips.txt (per-launch floors) + r05_layer_bytes_32clips.json
+# the bench line quotes the PMC traffic / per-launch byte list of the sources it runs from profiles/: put this call's files there first
+cp $O/r05_conv_traffic_32clips.json $O/r05_phase_traffic_32clips.json $O/r05_layer_bytes_32clips.json $O/r05_layer_table_32clips.txt $R/profiles/
 cd $R && python bench.py > $O/r05_bench_default.json 2> $O/r05_bench_default.err
