@@ -103,11 +103,14 @@ constexpr int CLD = 16;   // LDS row = one 16-float chunk; the four 16-byte slot
 //      ring slot is a compile-time constant that folds into the ds_read_b128 offset fields and into the M0 immediates of the DMA.  Why:
 //      tools/probes/valu_mfma_overlap.hip -- VALU issue time ADDS to matrix time on gfx950 (22 VALU instructions per 32 MFMAs in mode 3:
 //      fragment addresses, lane offsets + their out-of-range selects).  Same products in the same order: bit-identical to modes 3 / 6.
-//   9  (round 5) mode 5 for the 7x7 stem exactly (K = 7 x 24 = 168 -> 176: eleven chunks), fully unrolled: the tap offset of a lane's k-quad in
-//      chunk c -- row (4 c + kq) / 6 of the window, quad (4 c + kq) % 6 of that row -- is not separable into a lane part and a chunk part, so the
-//      22 byte offsets (11 chunks x 2 pieces) are computed once and held in registers; ring slots, the weight rows' k offset (scalar offset)
+//   9 / 10  (round 5) modes 5 / 2 for a FIXED chunk count, fully unrolled -- 9: the 7x7 stem (K = 7 x 24 = 168 -> 176: eleven chunks), 10: a 3x3
+//      layer on 24 channels (PhaseNet's first conv, K = 216 -> 224: fourteen chunks).  The tap offset of a lane's k-quad in chunk c is not
+//      separable into a lane part and a chunk part, so the byte offsets of every chunk (11 or 14 chunks x 2 pieces, out-of-range taps folded
+//      in) are computed once with the base mode's own tap walk and held in registers; ring slots, the weight rows' k offset (scalar offset)
 //      and the counted waits are compile-time constants.  Mode 5's loop spent ~28 vector instructions per 16 MFMAs on them.
-//      Rows past M read a valid row instead of zeros (their results are never stored), quads past K = 168 meet zero weights as in mode 5.
+//   11 (round 5) mode 1 (slice-major k) for 3x3 kernels: a chunk is one tap of one 16-channel slice, so the loop is unrolled by the nine taps
+//      (a multiple of the ring depth): the nine per-lane tap offsets (border taps folded in as out-of-range) are loop constants, the slice rides
+//      in the scalar offset of the buffer instructions.  Same products in the same order as the base modes: bit-identical.
 // (the scheduled 1x1 loop of the 128x128 tile would take 188 registers -- every fragment read of a step in flight at once -- where its mode-3
 //  twin's 156 keep three workgroups on a CU: held to three waves per SIMD.  The bf16x3 instantiations are held to the occupancy of their fp32 twins: the eight-wave one needs 133 registers where 128 keep two
 //  workgroups on a CU; the four-wave 128x256 one -- 64x128 wave tiles -- 280 where 256 keep two waves on a SIMD)
@@ -116,6 +119,7 @@ __global__ void __launch_bounds__(WGM * WGN * 64)
     __attribute__((amdgpu_waves_per_eu(X3 ? (WGM * WGN == 8 ? 4 : 2) : (KMODE >= 7 && WGM * WGN == 4 && BM * BN == 128 * 128) ? 3 : 1, 8)))
 conv_mfma_kernel(const ConvParams p) {
     constexpr int NW = WGM * WGN;                     // waves per workgroup: 4, or 8 for the 128x256 tile
+    constexpr int TMODE = KMODE == 9 ? 5 : KMODE == 10 ? 2 : KMODE == 11 ? 1 : KMODE;      // the tap walk a scheduled mode takes its offsets from
     static_assert(NW == 4 || NW == 8, "four or eight waves per workgroup");
     constexpr int WM = BM / WGM, WN = BN / WGN;
     constexpr int TM = WM / 32, TN = WN / 32;
@@ -156,7 +160,7 @@ conv_mfma_kernel(const ConvParams p) {
     const int tile_m = logical / p.tiles_n, tile_n = logical - tile_m * p.tiles_n;
     // hpool (the stem, KMODE 5 on the 128x64 tile): tiles start every BM - 2 rows -- a tile's last two pixels are computed again by the
     // next one, so that every 3-pixel pooling window that starts at an even pixel lies inside ONE tile (1.6 % more MFMA work)
-    const bool hpool = (KMODE == 5 || KMODE == 9) && BM == 128 && BN == 64 && p.hpool;
+    const bool hpool = TMODE == 5 && BM == 128 && BN == 64 && p.hpool;
     const int m_base = p.m_off + tile_m * (hpool ? BM - 2 : BM), n_base = tile_n * BN;
 
     // ---- operand fetch through buffer descriptors: the hardware range check returns 0 for any offset
@@ -211,12 +215,12 @@ conv_mfma_kernel(const ConvParams p) {
     //              chunks and is served by L1/L2 instead of the fabric (measured: conv4_x 3x3 fetched 8.5x its
     //              input with korder 0).
     int tk = kq * 4, tr, ts, tc;
-    const int rgq = (KMODE == 5 || KMODE == 9) ? (p.kw * 3 + 3) / 4 : 1;   // k-quads per kernel row (KMODE 5)
-    if (KMODE == 5 || KMODE == 9) {
+    const int rgq = TMODE == 5 ? (p.kw * 3 + 3) / 4 : 1;   // k-quads per kernel row (KMODE 5)
+    if (TMODE == 5) {
         tr = kq / rgq;
         ts = kq - tr * rgq;      // quad inside the row group
         tc = 0;
-    } else if (KMODE != 1) {
+    } else if (TMODE != 1) {
         const int rs = tk / p.Cin;
         tc = tk - rs * p.Cin;
         tr = rs / p.kw;
@@ -229,7 +233,7 @@ conv_mfma_kernel(const ConvParams p) {
     unsigned va[AIT];
     auto tap_offsets = [&]() {
         const bool kok = tk < p.K;
-        if (KMODE == 5) {
+        if (TMODE == 5) {
             const int tapoff = tr * p.W * 3 + ts * 4;
 #pragma unroll
             for (int it = 0; it < AIT; ++it) va[it] = (kok && a_ok[it]) ? (unsigned)(a_pix[it] + tapoff) * 4u : OOB;
@@ -256,19 +260,19 @@ conv_mfma_kernel(const ConvParams p) {
     };
     auto tap_advance = [&]() {
         tk += CBK;
-        if (KMODE == 0) {
+        if (TMODE == 0) {
             tc += CBK;
             while (tc >= p.Cin) {
                 tc -= p.Cin;
                 if (++ts == p.kw) { ts = 0; ++tr; }
             }
-        } else if (KMODE == 2) {
+        } else if (TMODE == 2) {
             tc += CBK;
             if (tc >= p.Cin) {
                 tc -= p.Cin;
                 if (++ts == p.kw) { ts = 0; ++tr; }
             }
-        } else if (KMODE == 1) {
+        } else if (TMODE == 1) {
             if (++ts == p.kw) {
                 ts = 0;
                 if (++tr == p.kh) { tr = 0; tc += CBK; }
@@ -276,7 +280,7 @@ conv_mfma_kernel(const ConvParams p) {
         } else if (KMODE == 4) {
             ts += CBK / 4;
             if (ts >= p.kw) { ts -= p.kw; ++tr; }
-        } else if (KMODE == 5) {
+        } else if (TMODE == 5) {
             ts += CBK / 4;
             while (ts >= rgq) { ts -= rgq; ++tr; }
         }
@@ -418,19 +422,21 @@ conv_mfma_kernel(const ConvParams p) {
         }
         if (nk - kc >= 1) step(std::integral_constant<int, 0>());
         if (nk - kc == 2) step(std::integral_constant<int, 1>());
-    } else if constexpr (KMODE == 9) {
-        static_assert(!ABL && !X3, "the scheduled stem loop has no measurement / bf16x3 form");
-        constexpr int NK = 11;                               // 7 kernel rows x 24 floats = 168 -> 176 (conv_forward checks)
-        unsigned vat[NK][AIT];
+    } else if constexpr (KMODE == 9 || KMODE == 10) {
+        static_assert(!ABL && !X3, "the unrolled loops have no measurement / bf16x3 form");
+        constexpr int NK = KMODE == 9 ? 11 : 14;             // 7 x 24 = 168 -> 176 floats; 9 x 24 = 216 -> 224 (conv_forward checks Kpad)
+        unsigned vat[NK][AIT], vb0[BIT];
 #pragma unroll
-        for (int c = 0; c < NK; ++c) {
-            const int g = 4 * c + kq, r = g / 6, q = g - 6 * r;
-            const int tapoff = r * p.W * 3 + q * 4;
+        for (int it = 0; it < BIT; ++it) vb0[it] = vb[it];   // (tap_advance also walks the weight offsets: the loop uses the scalar offset instead)
+#pragma unroll
+        for (int c = 0; c < NK; ++c) {                       // the base mode's own tap walk, once: same offsets, out-of-range taps included
+            tap_offsets();
 #pragma unroll
             for (int it = 0; it < AIT; ++it) {
-                vat[c][it] = (unsigned)(a_pix[it] + tapoff) * 4u;      // (rows past M: a_pix is row m_base's)
-                asm volatile("" : "+v"(vat[c][it]));                    // opaque: hipcc would otherwise sink the arithmetic back into the loop
+                vat[c][it] = va[it];
+                asm volatile("" : "+v"(vat[c][it]));         // opaque: hipcc would otherwise sink the arithmetic back into the loop
             }
+            tap_advance();
         }
         const unsigned wa0 = __builtin_amdgcn_readfirstlane(lds_a + (unsigned)(wave * 16 * CLD * 4));
         const unsigned wb0 = __builtin_amdgcn_readfirstlane(lds_b + (unsigned)(wave * 16 * CLD * 4));
@@ -448,7 +454,7 @@ conv_mfma_kernel(const ConvParams p) {
             });
             static_for<BIT>([&](auto it_tag) {
                 constexpr int IT = decltype(it_tag)::value;
-                piece9(rsrc_b, vb[IT], wb0, std::integral_constant<int, (SLOT * BN + IT * RPR) * CLD * 4>(), std::integral_constant<int, C_ * CBK * 4>());
+                piece9(rsrc_b, vb0[IT], wb0, std::integral_constant<int, (SLOT * BN + IT * RPR) * CLD * 4>(), std::integral_constant<int, C_ * CBK * 4>());
             });
         };
         int fao[TM][2], fbo[TN][2];
@@ -497,6 +503,95 @@ conv_mfma_kernel(const ConvParams p) {
             if constexpr (KC + 1 < NK)
                 asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" :: "n"(KC + 2 < NK ? NL : 0) : "memory");
         });
+    } else if constexpr (KMODE == 11) {
+        static_assert(!ABL && !X3, "the unrolled loops have no measurement / bf16x3 form");
+        // nine taps of slice 0 from mode 1's tap walk (tc = this lane's quad inside the slice; border taps and rows past M: out of range)
+        unsigned vt[9][AIT], vb0[BIT];
+#pragma unroll
+        for (int it = 0; it < BIT; ++it) vb0[it] = vb[it];
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            tap_offsets();
+#pragma unroll
+            for (int it = 0; it < AIT; ++it) {
+                vt[t][it] = va[it];
+                asm volatile("" : "+v"(vt[t][it]));
+            }
+            tap_advance();
+        }
+        const int nsl = nk / 9;                              // 16-channel slices
+        const unsigned wa0 = __builtin_amdgcn_readfirstlane(lds_a + (unsigned)(wave * 16 * CLD * 4));
+        const unsigned wb0 = __builtin_amdgcn_readfirstlane(lds_b + (unsigned)(wave * 16 * CLD * 4));
+        auto piece11 = [&](const __amdgpu_buffer_rsrc_t& rsrc, unsigned voff, unsigned soff, unsigned wbase, auto lds_tag) {
+            unsigned keep;
+            asm volatile("s_mov_b32 %0, m0\n\ts_add_u32 m0, %4, %5\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep) : "v"(voff), "s"(rsrc), "s"(soff), "s"(wbase), "n"(decltype(lds_tag)::value) : "memory", "scc");
+        };
+        // DMA of tap T of slice sl (chunk 9 sl + T) into ring slot T % 3 (9 is a multiple of the ring depth)
+        auto dma11 = [&](auto t_tag, int sl) {
+            constexpr int T = decltype(t_tag)::value, SLOT = T % NBUF;
+            // past the last slice the scalar offset would leave the tensors (the range check does not see it): zero records instead
+            const unsigned live = sl < nsl ? 0xFFFFFFFFu : 0u;
+            const unsigned so_a = __builtin_amdgcn_readfirstlane((unsigned)sl * (CBK * 4u));
+            const unsigned so_b = __builtin_amdgcn_readfirstlane((unsigned)(sl * 9 + T) * (CBK * 4u));
+            const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(in_b) + img0 * img_elems, 0, a_bytes & live, 0x00020000);
+            const __amdgpu_buffer_rsrc_t rb =
+                __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(w_b), 0, (unsigned)((int64_t)p.Cout * p.Kpad * 4) & live, 0x00020000);
+            static_for<AIT>([&](auto it_tag) {
+                constexpr int IT = decltype(it_tag)::value;
+                piece11(ra, vt[T][IT], so_a, wa0, std::integral_constant<int, (SLOT * BM + IT * RPR) * CLD * 4>());
+            });
+            static_for<BIT>([&](auto it_tag) {
+                constexpr int IT = decltype(it_tag)::value;
+                piece11(rb, vb0[IT], so_b, wb0, std::integral_constant<int, (SLOT * BN + IT * RPR) * CLD * 4>());
+            });
+        };
+        int fao[TM][2], fbo[TN][2];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int r = wm * WM + i * 32 + lr, g = (r >> 2) & 3;
+            fao[i][0] = r * CLD + (((2 * lh) ^ g) << 2);
+            fao[i][1] = r * CLD + (((2 * lh + 1) ^ g) << 2);
+        }
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int r = wn * WN + j * 32 + lr, g = (r >> 2) & 3;
+            fbo[j][0] = r * CLD + (((2 * lh) ^ g) << 2);
+            fbo[j][1] = r * CLD + (((2 * lh + 1) ^ g) << 2);
+        }
+        dma11(std::integral_constant<int, 0>(), 0);
+        dma11(std::integral_constant<int, 1>(), 0);
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" :: "n"(NL) : "memory");   // chunk 0 landed (chunk 1 still in flight)
+        for (int sl = 0; sl < nsl; ++sl) {
+            static_for<9>([&](auto t_tag) {
+                constexpr int T = decltype(t_tag)::value, BUF = T % NBUF;
+                dma11(std::integral_constant<int, (T + 2) % 9>(), T + 2 >= 9 ? sl + 1 : sl);
+                float4 qa[TM][2], qb[TN][2];
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    qa[i][0] = *reinterpret_cast<const float4*>(As + BUF * BM * CLD + fao[i][0]);
+                    qa[i][1] = *reinterpret_cast<const float4*>(As + BUF * BM * CLD + fao[i][1]);
+                }
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    qb[j][0] = *reinterpret_cast<const float4*>(Bs + BUF * BN * CLD + fbo[j][0]);
+                    qb[j][1] = *reinterpret_cast<const float4*>(Bs + BUF * BN * CLD + fbo[j][1]);
+                }
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+#pragma unroll
+                    for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+                        for (int i = 0; i < TM; ++i)
+#pragma unroll
+                            for (int j = 0; j < TN; ++j) {
+                                const float a = kk == 0 ? qa[i][h].x : kk == 1 ? qa[i][h].y : kk == 2 ? qa[i][h].z : qa[i][h].w;
+                                const float b = kk == 0 ? qb[j][h].x : kk == 1 ? qb[j][h].y : kk == 2 ? qb[j][h].z : qb[j][h].w;
+                                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[i][j], 0, 0, 0);
+                            }
+                asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" :: "n"(NL) : "memory");
+            });
+        }
     } else {
     tap_offsets();
     dma(0);
@@ -616,7 +711,7 @@ conv_mfma_kernel(const ConvParams p) {
     // image row: the ceil-mode window at the right border has two columns) and writes pooled pixel m / 2 -- [B, Ho, Wo / 2, 64], half the
     // bytes, and the kernel that finishes the pool (pool_reduce.hip, hp = 1) reads three rows per pixel instead of nine pixels.
     // max is exact and order-free: the pooled tensor is bit-identical to pooling the full stem output.
-    if constexpr ((KMODE == 5 || KMODE == 9) && BM == 128 && BN == 64) {
+    if constexpr (TMODE == 5 && BM == 128 && BN == 64) {
         if (hpool) {
             static_assert(TN == 1 && WN == 32, "one 32-channel accumulator column per wave");
             constexpr int TLD = BN + 4;                          // row stride of the staged tile (floats): 16-byte aligned rows, odd in 16-byte units
@@ -809,8 +904,20 @@ static int launch_cfg(const ConvParams& p, hipStream_t stream) {
     if (p.sched1x1) return launch_km<BM, BN, WGM, WGN, 7>(p, stream);
     if (p.in2) return launch_km<BM, BN, WGM, WGN, 6>(p, stream);
     if (p.kh == 1 && p.kw == 1 && p.pad == 0) return launch_km<BM, BN, WGM, WGN, 3>(p, stream);
-    if (p.korder == 1) return launch_km<BM, BN, WGM, WGN, 1>(p, stream);
-    if (p.Cin >= CBK) return launch_km<BM, BN, WGM, WGN, 2>(p, stream);
+    if (p.korder == 1) {
+        // 3x3 kernels on slice-major k: the loop unrolled by the nine taps (mode 11) unless the caller asks for the twin
+        if constexpr (BM == 128 && (BN == 64 || BN == 128) && WGM * WGN == 4) {
+            if (!p.no_sched && p.kh == 3 && p.kw == 3 && p.K == p.Kpad && p.batch <= 1 && p.force_tile < 16) return launch_km<BM, BN, WGM, WGN, 11>(p, stream);
+        }
+        return launch_km<BM, BN, WGM, WGN, 1>(p, stream);
+    }
+    if (p.Cin >= CBK) {
+        // fourteen chunks exactly (3x3 on 24 channels: PhaseNet's first conv): fully unrolled with precomputed tap offsets (mode 10)
+        if constexpr (BM == 128 && BN == 64) {
+            if (!p.no_sched && p.Kpad == 224 && p.batch <= 1 && p.force_tile < 16) return launch_km<BM, BN, WGM, WGN, 10>(p, stream);
+        }
+        return launch_km<BM, BN, WGM, WGN, 2>(p, stream);
+    }
     if (p.Cin == 4 && p.kw >= 4) return launch_km<BM, BN, WGM, WGN, 4>(p, stream);
     return launch_km<BM, BN, WGM, WGN, 0>(p, stream);
 }

@@ -321,6 +321,7 @@ struct mm_head {
     mm::Layer conv[6], fc1, fc2, transform, gru_ih[2], gru_hh[2][2], classifier;
     float* bhh[2][2];
     int winograd;   // 1 (default): PhaseNet's 128 -> 256 3x3 layer through the fused F(4x4,3x3) kernel; MM_HEAD_WINOGRAD=0: direct form
+    int no_sched;   // MM_CONV_SCHED=0 at create time: the conv engine's base loops instead of the scheduled ones (modes 7, 10, 11): the parity twin
     int pc;         // PhaseNet input channels = 2 * num_phase (api/mimamo_net.py:112): 24 for the published model
     int pcp;        // pc rounded up to a multiple of 4: channel stride of the NHWC phase buffers (== pc unless num_phase is odd)
     int device;
@@ -706,6 +707,8 @@ int mm_head_create_cfg(mm_head_t** out, const float* blob, int64_t n_floats, int
     {
         const char* e = getenv("MM_HEAD_WINOGRAD");   // measurement knob
         h->winograd = e ? atoi(e) : 1;
+        const char* cs = getenv("MM_CONV_SCHED");     // measurement knob / parity twin, as in mm_resnet50_create
+        h->no_sched = cs ? atoi(cs) == 0 : 0;
     }
     h->feat_dim = units[0];
     h->mlp_max = 256;
@@ -821,22 +824,22 @@ int mm_head_forward(mm_head_t* h, const float* phase_0, const float* phase_1, in
         MM_HIP(hipMemcpy2DAsync(cat + 64, catc * sizeof(float), phase_1, pc * sizeof(float), pc * sizeof(float),
                                 (size_t)N64 * 24 * 24, hipMemcpyDeviceToDevice, s));
     }
-    MM_TRY(run_layer(h->conv[0], x0, N, 48, 48, pcp, 0, a0, 64, 0, nullptr, 0, s));
-    MM_TRY(run_layer(h->conv[1], a0, N, 48, 48, 64, 0, cat, catc, 0, nullptr, 0, s));
+    MM_TRY(run_layer(h->conv[0], x0, N, 48, 48, pcp, 0, a0, 64, 0, nullptr, 0, s, nullptr, nullptr, 0, h->no_sched));
+    MM_TRY(run_layer(h->conv[1], a0, N, 48, 48, 64, 0, cat, catc, 0, nullptr, 0, s, nullptr, nullptr, 0, h->no_sched));
     // the fused Winograd kernel declines (MM_ERR_UNSUPPORTED) what its 32-bit plane offsets cannot address: direct form then
     rc = MM_ERR_UNSUPPORTED;
     if (h->winograd && h->conv[2].wino_u4) rc = run_layer_wino(h->conv[2], cat, N, 24, 24, a1, wv, nullptr, 5, s);   // K = 88 padded to 128
-    if (rc == MM_ERR_UNSUPPORTED) rc = run_layer(h->conv[2], cat, N, 24, 24, catc, 0, a1, 128, 0, nullptr, 0, s);
+    if (rc == MM_ERR_UNSUPPORTED) rc = run_layer(h->conv[2], cat, N, 24, 24, catc, 0, a1, 128, 0, nullptr, 0, s, nullptr, nullptr, 0, h->no_sched);
     if (rc != MM_OK) return rc;
-    MM_TRY(run_layer(h->conv[3], a1, N, 24, 24, 128, 0, a2, 128, 0, nullptr, 0, s));
+    MM_TRY(run_layer(h->conv[3], a1, N, 24, 24, 128, 0, a2, 128, 0, nullptr, 0, s, nullptr, nullptr, 0, h->no_sched));
     rc = MM_ERR_UNSUPPORTED;
     if (h->winograd && h->conv[4].wino_u4) rc = run_layer_wino(h->conv[4], a2, N, 12, 12, a3, wv, nullptr, 5, s);   // 3x3 tiles per map
-    if (rc == MM_ERR_UNSUPPORTED) rc = run_layer(h->conv[4], a2, N, 12, 12, 128, 0, a3, 256, 0, nullptr, 0, s);
+    if (rc == MM_ERR_UNSUPPORTED) rc = run_layer(h->conv[4], a2, N, 12, 12, 128, 0, a3, 256, 0, nullptr, 0, s, nullptr, nullptr, 0, h->no_sched);
     if (rc != MM_OK) return rc;
-    MM_TRY(run_layer(h->conv[5], a3, N, 12, 12, 256, 0, a4, 256, 0, nullptr, 0, s));
+    MM_TRY(run_layer(h->conv[5], a3, N, 12, 12, 256, 0, a4, 256, 0, nullptr, 0, s, nullptr, nullptr, 0, h->no_sched));
     MM_TRY(avgpool_hw(a4, pool, N64, 36, 256, 256, 0, 0, s));
-    MM_TRY(run_layer(h->fc1, pool, N, 1, 1, 256, 0, fc1, 256, 0, nullptr, 0, s));
-    MM_TRY(run_layer(h->fc2, fc1, N, 1, 1, 256, 0, feat, 512, 256, nullptr, 0, s));  // cat([spatial, temporal]) (:136)
+    MM_TRY(run_layer(h->fc1, pool, N, 1, 1, 256, 0, fc1, 256, 0, nullptr, 0, s, nullptr, nullptr, 0, h->no_sched));
+    MM_TRY(run_layer(h->fc2, fc1, N, 1, 1, 256, 0, feat, 512, 256, nullptr, 0, s, nullptr, nullptr, 0, h->no_sched));  // cat([spatial, temporal]) (:136)
     // ---- spatial stream: MLP (:22-26)
     {
         const float* xin = rgb;
@@ -844,19 +847,19 @@ int mm_head_forward(mm_head_t* h, const float* phase_0, const float* phase_1, in
         for (size_t i = 0; i < h->mlp.size(); ++i) {
             const bool last = i + 1 == h->mlp.size();
             float* dst = last ? feat : m1 + (i & 1) * N64 * h->mlp_max;     // the last layer writes the spatial half of `feat`
-            MM_TRY(run_layer(h->mlp[i], xin, N, 1, 1, cin, 0, dst, last ? 512 : h->mlp[i].cout, 0, nullptr, 0, s));
+            MM_TRY(run_layer(h->mlp[i], xin, N, 1, 1, cin, 0, dst, last ? 512 : h->mlp[i].cout, 0, nullptr, 0, s, nullptr, nullptr, 0, h->no_sched));
             xin = dst;
             cin = h->mlp[i].cout;
         }
     }
-    MM_TRY(run_layer(h->transform, feat, N, 1, 1, 512, 0, f, 256, 0, nullptr, 0, s));
+    MM_TRY(run_layer(h->transform, feat, N, 1, 1, 512, 0, f, 256, 0, nullptr, 0, s, nullptr, nullptr, 0, h->no_sched));
     // ---- nn.GRU(256,128,bidirectional,num_layers=2) WITHOUT batch_first: the [bs,T,256] tensor is read as
     //      (seq_len = bs, batch = T)  (:119,139 -- quirk Q1, trained in, reproduced on purpose)
     const int Ti = (int)T, S = (int)bs;
     const float* x = f;
     float* lay[2] = {l0, l1};
     for (int l = 0; l < 2; ++l) {
-        MM_TRY(run_layer(h->gru_ih[l], x, N, 1, 1, 256, 0, gi, 768, 0, nullptr, 0, s));
+        MM_TRY(run_layer(h->gru_ih[l], x, N, 1, 1, 256, 0, gi, 768, 0, nullptr, 0, s, nullptr, nullptr, 0, h->no_sched));
         for (int d = 0; d < 2; ++d) {
             for (int step = 0; step < S; ++step) {
                 const int t = d == 0 ? step : S - 1 - step;
@@ -867,14 +870,14 @@ int mm_head_forward(mm_head_t* h, const float* phase_0, const float* phase_1, in
                 } else {
                     const int tp = d == 0 ? t - 1 : t + 1;
                     const float* hprev = lay[l] + (int64_t)tp * Ti * 256;
-                    MM_TRY(run_layer(h->gru_hh[l][d], hprev, Ti, 1, 1, 256, d * 128, gh, 384, 0, nullptr, 0, s));
+                    MM_TRY(run_layer(h->gru_hh[l][d], hprev, Ti, 1, 1, 256, d * 128, gh, 384, 0, nullptr, 0, s, nullptr, nullptr, 0, h->no_sched));
                     MM_TRY(gru_gates(git, 768, d * 384, gh, nullptr, hprev, 256, d * 128, hout, 256, d * 128, Ti, 128, s));
                 }
             }
         }
         x = lay[l];
     }
-    MM_TRY(run_layer(h->classifier, l1, N, 1, 1, 256, 0, out, 2, 0, nullptr, 0, s));
+    MM_TRY(run_layer(h->classifier, l1, N, 1, 1, 256, 0, out, 2, 0, nullptr, 0, s, nullptr, nullptr, 0, h->no_sched));
 #undef MM_TRY
     return MM_OK;
 }

@@ -58,6 +58,9 @@ CASES = [
     (1, 9, 9, 32, 48, 5, 1, 2, 0, 1),        # 5x5 taps, pad 2
     (3, 14, 14, 64, 256, 1, 1, 0, 1, 5),     # 128x256 tile, eight waves: M = 588 (ragged), one n-tile
     (2, 10, 10, 72, 320, 1, 2, 0, 0, 5),     # 128x256 tile: strided 1x1, K = 72 (tail), N = 320 (ragged second n-tile)
+    (2, 14, 14, 24, 64, 3, 1, 1, 1, 2),      # K = 216 -> 224 on the 128x64 tile: the fourteen-chunk unrolled loop (KMODE 10), M = 392 (ragged)
+    (2, 15, 15, 64, 64, 3, 2, 1, 1, 2),      # 3x3 stride 2 on 128x64; slice-major: the nine-tap unrolled loop (KMODE 11), four slices
+    (3, 13, 13, 32, 128, 3, 2, 1, 0, 1),     # ... on 128x128, two slices, M = 147 (ragged)
 ]
 
 
@@ -677,6 +680,25 @@ def test_conv_engine_scheduled_1x1_loop_is_bit_identical_to_modes_3_and_6(resnet
         twin.close()
         if env:
             monkeypatch.delenv(env[0])
+
+
+def test_head_scheduled_conv_loops_are_bit_identical_to_the_base_modes(head, dev, monkeypatch):
+    """Round 5: PhaseNet's first conv (3x3 on 24 channels, K = 216 -> 224) runs the engine's fourteen-chunk unrolled loop (KMODE 10: every
+    chunk's tap offsets precomputed with mode 2's own tap walk), its stride-2 3x3 layers the nine-tap unrolled slice-major loop (KMODE 11:
+    nine per-lane tap offsets, the slice in the scalar offset), the Linear / GRU products mode 7.  MM_CONV_SCHED=0 at create time keeps
+    modes 2 / 1 / 3: same products in the same order -> the same bits, for several batch sizes (ragged last tiles)."""
+    from mimamo_net_amd.mimamo_net import Two_Stream_RNN
+    sd = weights.make_two_stream_state_dict(seed=3)
+    monkeypatch.setenv("MM_CONV_SCHED", "0")
+    twin = Two_Stream_RNN().load_state_dict(sd).eval().to(dev)
+    for bs, t in ((1, 3), (2, 16), (1, 1)):
+        p0, p1, rgb = _head_inputs(bs, t, 57)
+        args = [[torch.from_numpy(p0).to(dev), torch.from_numpy(p1).to(dev)], torch.from_numpy(rgb).to(dev)]
+        b = twin(*args)                      # (the twin's handle is built on first use, under the environment variable)
+        a = head(*args)
+        assert torch.isfinite(a).all()
+        assert torch.equal(a, b), (bs, t, (a - b).abs().max().item())
+    monkeypatch.delenv("MM_CONV_SCHED")
 
 
 def test_resnet50_bf16x3_mode(resnet, oracle, dev):
