@@ -130,8 +130,8 @@ preproc_gray_kernel(const uint8_t* __restrict__ frames, int S, int G, int ksize,
 constexpr int RGB_ROWS = 16, RGB_MAX_IN = 24;
 __global__ void __launch_bounds__(256)
 preproc_rgb3_kernel(const uint8_t* __restrict__ frames, int S, int R, int C, int ksize, const int* __restrict__ bounds,
-                    const int* __restrict__ kk, float mean0, float mean1, float mean2, float* __restrict__ out) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char hrow[];      // [n_in][C][3] uint8
+                    const int* __restrict__ kk, float mean0, float mean1, float mean2, float* __restrict__ out, int max_in) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char hrow[];      // [max_in][C][3] uint8, then the staged source rows [max_in][S][3]
     const int64_t n = blockIdx.x;
     const int row0 = blockIdx.y * RGB_ROWS;
     const int off = (int)rintf((R - C) / 2.0f);  // CenterCrop: int(round((256-224)/2.)) = 16
@@ -152,22 +152,40 @@ preproc_rgb3_kernel(const uint8_t* __restrict__ frames, int S, int R, int C, int
     const int yy_first = row0 + off, yy_last = row0 + rows - 1 + off;
     const int in_lo = bounds[yy_first * 2];
     const int n_in = bounds[yy_last * 2] + bounds[yy_last * 2 + 1] - in_lo;
+    // (round 5) the block's source rows -- one contiguous range of the frame -- come into LDS as coalesced words first, and a thread keeps its
+    // output column's bounds and weights in registers over the rows: the first version chased bounds -> weights -> source bytes through
+    // global memory for every (row, column) item, nine dependent rounds of L2 latency per thread
+    unsigned char* srow = hrow + ((max_in * C * 3 + 15) & ~15);               // [n_in][S][3] uint8
+    {
+        const uint8_t* s0 = src + (int64_t)in_lo * S * 3;
+        const int nb = n_in * S * 3;
+        if (((nb | (S * 3)) & 3) == 0 && (reinterpret_cast<uintptr_t>(s0) & 3) == 0) {
+            for (int i = threadIdx.x; i < nb / 4; i += 256) reinterpret_cast<unsigned*>(srow)[i] = reinterpret_cast<const unsigned*>(s0)[i];
+        } else {
+            for (int i = threadIdx.x; i < nb; i += 256) srow[i] = s0[i];
+        }
+    }
+    __syncthreads();
     // horizontal pass, once per (input row, cropped output column)
-    for (int i = threadIdx.x; i < n_in * C; i += 256) {
-        const int r = i / C, cx = i - r * C;
+    for (int cx = threadIdx.x; cx < C; cx += 256) {
         const int xx = cx + off;
         const int xmin = bounds[xx * 2], xcnt = bounds[xx * 2 + 1];
-        const int* kx = kk + xx * ksize;
-        const uint8_t* rowp = src + ((int64_t)(in_lo + r) * S + xmin) * 3;
-        int a0 = 1 << (PRECISION_BITS - 1), a1 = a0, a2 = a0;
-        for (int x = 0; x < xcnt; ++x) {
-            const int w = kx[x];
-            a0 += (int)rowp[x * 3] * w;
-            a1 += (int)rowp[x * 3 + 1] * w;
-            a2 += (int)rowp[x * 3 + 2] * w;
+        int kx[4];
+#pragma unroll
+        for (int x = 0; x < 4; ++x) kx[x] = x < ksize ? kk[xx * ksize + x] : 0;      // (ksize <= 4: checked by the launcher)
+        for (int r = 0; r < n_in; ++r) {
+            const unsigned char* rowp = srow + (r * S + xmin) * 3;
+            int a0 = 1 << (PRECISION_BITS - 1), a1 = a0, a2 = a0;
+#pragma unroll
+            for (int x = 0; x < 4; ++x)
+                if (x < xcnt) {
+                    a0 += (int)rowp[x * 3] * kx[x];
+                    a1 += (int)rowp[x * 3 + 1] * kx[x];
+                    a2 += (int)rowp[x * 3 + 2] * kx[x];
+                }
+            unsigned char* h = hrow + (r * C + cx) * 3;
+            h[0] = (unsigned char)clip8(a0); h[1] = (unsigned char)clip8(a1); h[2] = (unsigned char)clip8(a2);
         }
-        unsigned char* h = hrow + (r * C + cx) * 3;
-        h[0] = (unsigned char)clip8(a0); h[1] = (unsigned char)clip8(a1); h[2] = (unsigned char)clip8(a2);
     }
     // per-row vertical taps and the epilogue as a table: the reference's ToTensor (/255), *255.0, -mean are three separately rounded
     // fp32 operations of a uint8 value -- 256 possible results per channel, evaluated once per block with contraction off
@@ -379,12 +397,13 @@ int mm_preproc_forward(mm_preproc_t* h, const uint8_t* frames, int64_t n, float*
         // rows of the block after the horizontal pass: rgb3_max_in (exact, from the bounds table at create) input rows x crop
         // columns x 3 bytes of LDS; the kernel's tap arrays hold four vertical taps
         const int max_in = h->rgb3_max_in;
-        if (max_in <= 0 || max_in > mm::RGB_MAX_IN || h->bil.ksize > 4 || (int64_t)max_in * h->crop * 3 > 60 * 1024)
+        const int64_t rgb3_lds = (((int64_t)max_in * h->crop * 3 + 15) & ~15) + (int64_t)max_in * h->in_size * 3 + 16;
+        if (max_in <= 0 || max_in > mm::RGB_MAX_IN || h->bil.ksize > 4 || rgb3_lds > 60 * 1024)
             return MM_ERR_UNSUPPORTED;   // (a down-scaling resize: not the reference's 112 -> 256)
         dim3 grid((unsigned)n, (unsigned)((h->crop + mm::RGB_ROWS - 1) / mm::RGB_ROWS));
         mm::prof_before(4, (double)n * (3.0 * h->in_size * h->in_size + 12.0 * (h->crop + 6) * (h->crop + 6)), s, "preproc_rgb3");
-        hipLaunchKernelGGL(mm::preproc_rgb3_kernel, grid, dim3(256), max_in * h->crop * 3, s, frames, h->in_size, h->resize, h->crop,
-                           h->bil.ksize, h->d_bil_bounds, h->d_bil_kk, h->mean[0], h->mean[1], h->mean[2], rgb_out);
+        hipLaunchKernelGGL(mm::preproc_rgb3_kernel, grid, dim3(256), (int)rgb3_lds, s, frames, h->in_size, h->resize, h->crop,
+                           h->bil.ksize, h->d_bil_bounds, h->d_bil_kk, h->mean[0], h->mean[1], h->mean[2], rgb_out, max_in);
         mm::prof_after(4, s);
         MM_LAUNCH_CHECK();
     } else if (rgb_out) {
