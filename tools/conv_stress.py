@@ -37,6 +37,8 @@ if __name__ == "__main__":
         total += stress(1600000, 1, 64, 64, 1, tile, 12)
         total += stress(400000, 1, 16, 64, 1, tile, 20)
         total += stress(100000, 1, 256, 128, 1, tile, 20)
-        total += stress(512, 28, 64, 64, 3, tile, 12, 1)
+        total += stress(512, 28, 64, 64, 3, tile, 12, 1)      # (tiles 2 / 1: the nine-tap unrolled loop, KMODE 11)
+    total += stress(1024, 48, 24, 64, 3, 2, 12, 0)             # the fourteen-chunk unrolled loop (KMODE 10)
+    total += stress(2048, 24, 128, 128, 3, 1, 12, 1)           # KMODE 11 on 128x128, eight slices
     print("TOTAL differing runs:", total)
     sys.exit(1 if total else 0)
