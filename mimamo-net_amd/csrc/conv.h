@@ -36,6 +36,9 @@ struct ConvParams {
     int sched1x1;    // set by conv_forward: 1x1 layer with K % 16 == 0 on the scheduled loop (conv_mfma.hip KMODE 7 / 8)
     int no_sched;    // 1: keep modes 3 / 6 for such a layer (the parity twin of the scheduled loop)
     int x3;          // 1: 1x1 layer on the bf16 matrix pipes through a three-way bf16 split of both fp32 operands (conv_mfma.hip X3; `extra` only)
+    // exact division of a row index m < 2^31 by Ho * Wo and by Wo as multiply-high + shift (filled by conv_forward; the emulated 32-bit divisions of
+    // the tile prologue were a third of its vector instructions, and vector instructions are matrix time on this chip)
+    unsigned div_hw_mul, div_hw_sh, div_wo_mul, div_wo_sh;
     int hpool;       // 1 (korder 2 -- the stem -- with Cout == 64, Wo even, out_cstride == 64 only): the epilogue writes the HORIZONTAL half of
                      // MaxPool2d(3, 2, pad 0): out [B, Ho, Wo / 2, 64], out(b, y, j) = max over x in {2j, 2j+1, 2j+2 (if < Wo)} of relu(conv + bias)
                      // -- half the bytes; maxpool_reduce64(..., hp = 1) finishes the pool vertically (round 5, conv_mfma.hip "hpool")

@@ -80,6 +80,20 @@ __device__ __forceinline__ void split_bf16x3(const float4& q0, const float4& q1,
     }
 }
 
+// m / d for 0 <= m < 2^31 with (mul, sh) from fastdiv_make(d): q = (m * mul) >> (31 + L), L = ceil(log2 d), mul = ceil(2^(31 + L) / d) < 2^32
+// (Granlund-Montgomery for 31-bit dividends: exact).  d == 1: mul = 0 marks the identity.
+__device__ __forceinline__ int fastdiv(int m, unsigned mul, unsigned sh) {
+    return mul ? (int)(__umulhi((unsigned)m, mul) >> sh) : m;
+}
+static void fastdiv_make(int d, unsigned& mul, unsigned& sh) {
+    if (d <= 1) { mul = 0; sh = 0; return; }
+    int L = 0;
+    while ((1ll << L) < d) ++L;
+    const unsigned long long num = 1ull << (31 + L);
+    mul = (unsigned)((num + (unsigned long long)d - 1) / (unsigned long long)d);      // < 2^32 because d > 2^(L - 1)
+    sh = (unsigned)(L - 1);                                                            // (m * mul) >> 32 >> (L - 1)
+}
+
 constexpr int CBK = 16;   // k-chunk
 constexpr int CLD = 16;   // LDS row = one 16-float chunk; the four 16-byte slots of a row are XOR-swizzled
 
@@ -168,7 +182,7 @@ conv_mfma_kernel(const ConvParams p) {
     //      branches or selects on the data.  The A descriptor is rebased to the first image this block
     //      touches so 32-bit byte offsets always suffice (a block spans a handful of images).
     const int hw_out = p.Ho * p.Wo;
-    const int img0 = m_base / hw_out;                                  // wave-uniform
+    const int img0 = fastdiv(m_base, p.div_hw_mul, p.div_hw_sh);       // wave-uniform
     const int64_t img_elems = (int64_t)p.H * p.W * p.in_cstride;
     const int64_t rem_elems = ((int64_t)p.B - img0) * img_elems;
     const unsigned a_bytes = rem_elems * 4 > 0xFFFFF000ll ? 0xFFFFF000u : (unsigned)(rem_elems * 4);
@@ -193,8 +207,8 @@ conv_mfma_kernel(const ConvParams p) {
         const int m = m_base + lrow + it * RPR;
         a_ok[it] = m < p.M;
         const int mm_ = a_ok[it] ? m : m_base;
-        const int b = mm_ / hw_out, rem = mm_ - b * hw_out;
-        const int ho = rem / p.Wo, wo = rem - ho * p.Wo;
+        const int b = fastdiv(mm_, p.div_hw_mul, p.div_hw_sh), rem = mm_ - b * hw_out;
+        const int ho = fastdiv(rem, p.div_wo_mul, p.div_wo_sh), wo = rem - ho * p.Wo;
         a_hi0[it] = ho * p.stride - p.pad;
         a_wi0[it] = wo * p.stride - p.pad;
         // element offset of tap (0,0), channel 0, relative to the descriptor base (may be negative: padding)
@@ -425,9 +439,25 @@ conv_mfma_kernel(const ConvParams p) {
     } else if constexpr (KMODE == 9 || KMODE == 10) {
         static_assert(!ABL && !X3, "the unrolled loops have no measurement / bf16x3 form");
         constexpr int NK = KMODE == 9 ? 11 : 14;             // 7 x 24 = 168 -> 176 floats; 9 x 24 = 216 -> 224 (conv_forward checks Kpad)
-        unsigned vat[NK][AIT], vb0[BIT];
+        unsigned vat[KMODE == 9 ? 2 : NK][AIT], vb0[BIT];
 #pragma unroll
         for (int it = 0; it < BIT; ++it) vb0[it] = vb[it];   // (tap_advance also walks the weight offsets: the loop uses the scalar offset instead)
+        if constexpr (KMODE == 9) {
+            // The stem's tap walk in closed form.  Quad g = 4 c + kq of the 6-quad kernel rows: row g / 6, quad g % 6.  4 c mod 6 is 0, 4, 2 for
+            // c = 0, 1, 2 (mod 3): only in chunks c = 1 (mod 3) do the lanes with kq >= 2 sit one kernel row below the others.  So a lane needs
+            // TWO offsets per piece -- vat[0] (its pixel + kq quads) and vat[1] (the same + one image row - 6 quads for kq >= 2) -- and the chunk
+            // part (row0(c) image rows + the first quad of the chunk) is wave-uniform and rides in the buffer instruction's scalar offset: no
+            // per-chunk vector instruction, 4 instead of 22 offset registers.  (Rows past M read row m_base's pixels -- their results are never
+            // stored --, quads past K = 168 read the next window row and meet zero weights; the first version of mode 9 walked the taps like
+            // mode 5 does: ~220 vector instructions per tile for an 11-chunk main loop.)
+            const int rowq = p.W * 3;                        // floats per image row
+#pragma unroll
+            for (int it = 0; it < AIT; ++it) {
+                vat[0][it] = (unsigned)(a_pix[it] + kq * 4) * 4u;
+                vat[1][it] = (unsigned)(a_pix[it] + kq * 4 + (kq >= 2 ? rowq - 24 : 0)) * 4u;
+                asm volatile("" : "+v"(vat[0][it]), "+v"(vat[1][it]));
+            }
+        } else {
 #pragma unroll
         for (int c = 0; c < NK; ++c) {                       // the base mode's own tap walk, once: same offsets, out-of-range taps included
             tap_offsets();
@@ -438,23 +468,26 @@ conv_mfma_kernel(const ConvParams p) {
             }
             tap_advance();
         }
+        }
         const unsigned wa0 = __builtin_amdgcn_readfirstlane(lds_a + (unsigned)(wave * 16 * CLD * 4));
         const unsigned wb0 = __builtin_amdgcn_readfirstlane(lds_b + (unsigned)(wave * 16 * CLD * 4));
-        auto piece9 = [&](const __amdgpu_buffer_rsrc_t& rsrc, unsigned voff, unsigned wbase, auto lds_tag, auto k_tag) {
+        auto piece9 = [&](const __amdgpu_buffer_rsrc_t& rsrc, unsigned voff, unsigned wbase, auto lds_tag, unsigned soff) {
             unsigned keep;
             // (the k offset of the weight rows rides in the SCALAR offset: the instruction's offset field would also move the LDS address)
             asm volatile("s_mov_b32 %0, m0\n\ts_add_u32 m0, %3, %4\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %5 offen lds\n\ts_mov_b32 m0, %0"
-                         : "=&s"(keep) : "v"(voff), "s"(rsrc), "s"(wbase), "n"(decltype(lds_tag)::value), "s"((unsigned)decltype(k_tag)::value) : "memory", "scc");
+                         : "=&s"(keep) : "v"(voff), "s"(rsrc), "s"(wbase), "n"(decltype(lds_tag)::value), "s"(soff) : "memory", "scc");
         };
         auto dma9 = [&](auto c_tag) {
             constexpr int C_ = decltype(c_tag)::value, SLOT = C_ % NBUF;
+            // mode 9: the chunk's wave-uniform part -- kernel row (4 C) / 6 and first quad (4 C) % 6 of the chunk -- as a scalar byte offset
+            const unsigned so_a = KMODE == 9 ? (unsigned)(((4 * C_) / 6) * (p.W * 3) + ((4 * C_) % 6) * 4) * 4u : 0u;
             static_for<AIT>([&](auto it_tag) {
                 constexpr int IT = decltype(it_tag)::value;
-                piece9(rsrc_a, vat[C_][IT], wa0, std::integral_constant<int, (SLOT * BM + IT * RPR) * CLD * 4>(), std::integral_constant<int, 0>());
+                piece9(rsrc_a, vat[KMODE == 9 ? (C_ % 3 == 1 ? 1 : 0) : C_][IT], wa0, std::integral_constant<int, (SLOT * BM + IT * RPR) * CLD * 4>(), so_a);
             });
             static_for<BIT>([&](auto it_tag) {
                 constexpr int IT = decltype(it_tag)::value;
-                piece9(rsrc_b, vb0[IT], wb0, std::integral_constant<int, (SLOT * BN + IT * RPR) * CLD * 4>(), std::integral_constant<int, C_ * CBK * 4>());
+                piece9(rsrc_b, vb0[IT], wb0, std::integral_constant<int, (SLOT * BN + IT * RPR) * CLD * 4>(), (unsigned)(C_ * CBK * 4));
             });
         };
         int fao[TM][2], fbo[TN][2];
@@ -736,7 +769,7 @@ conv_mfma_kernel(const ConvParams p) {
                 const float4 b = *reinterpret_cast<const float4*>(T + (2 * u + 1) * TLD + 4 * q);
                 const float4 c = *reinterpret_cast<const float4*>(T + (2 * u + 2) * TLD + 4 * q);
                 f32x4_t o = {fmaxf(a.x, b.x), fmaxf(a.y, b.y), fmaxf(a.z, b.z), fmaxf(a.w, b.w)};
-                if (m % p.Wo != p.Wo - 2) o = f32x4_t{fmaxf(o[0], c.x), fmaxf(o[1], c.y), fmaxf(o[2], c.z), fmaxf(o[3], c.w)};
+                if (m - fastdiv(m, p.div_wo_mul, p.div_wo_sh) * p.Wo != p.Wo - 2) o = f32x4_t{fmaxf(o[0], c.x), fmaxf(o[1], c.y), fmaxf(o[2], c.z), fmaxf(o[3], c.w)};
                 __builtin_nontemporal_store(o, reinterpret_cast<f32x4_t*>(out_b + (int64_t)(m >> 1) * BN + 4 * q));
             }
             return;
@@ -870,6 +903,8 @@ static int num_cus() {
 
 template <int BM, int BN, int WGM, int WGN, int KMODE, bool ABL = false, bool X3 = false>
 static int launch_km(ConvParams p, hipStream_t stream) {
+    fastdiv_make(p.Ho * p.Wo, p.div_hw_mul, p.div_hw_sh);
+    fastdiv_make(p.Wo, p.div_wo_mul, p.div_wo_sh);
     p.tiles_m = (p.M - p.m_off + BM - 1) / BM;
     if (p.hpool) p.tiles_m = (p.M / 2 + (BM / 2 - 1) - 1) / (BM / 2 - 1);     // BM / 2 - 1 pooled pixels per tile (tiles overlap by two rows)
     p.tiles_n = (p.Cout + BN - 1) / BN;
