@@ -343,6 +343,23 @@ def test_profiles_hold_pmc_summaries_for_the_head_kernel_sources():
     assert len(lb["launches"]) > 90 and 0.5 < lb["mixed_frac"] < 1.0 and lb["step_floor_ms"] > 60
 
 
+def test_every_profile_file_the_docs_quote_exists():
+    """DESIGN.md / README.md / INTEGRATION.md and the profiles / tools indexes back their numbers with files under profiles/ (same-box A/B
+    logs, rocprof summaries): a renamed or dropped log must not leave a dangling citation behind."""
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    missing = []
+    for doc in ("DESIGN.md", "README.md", "INTEGRATION.md", os.path.join("profiles", "README.md"), os.path.join("tools", "README.md")):
+        text = open(os.path.join(root, doc)).read()
+        for m in re.finditer(r"(r0[1-9]_[A-Za-z0-9_.{},|*]+?\.(?:txt|json|csv|md))", text):
+            name = m.group(1)
+            if any(c in name for c in "{}*|,"):
+                continue                       # a pattern (r04_{conv,phase}_traffic_...), not a file name
+            if not os.path.exists(os.path.join(root, "profiles", name)):
+                missing.append((doc, name))
+    assert not missing, missing
+
+
 MODEL_DEF = """
 import torch
 import torch.nn as nn
