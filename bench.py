@@ -46,6 +46,57 @@ FRAMES_PER_CLIP = 64
 EXAMPLE_VIDEO_FRAMES = 309      # api/readme.md:100 (utterance_1.mp4): 5 snippets of 64 (snippet_sampler.py:112-126)
 
 
+def measure_live_traffic(args, per_step):
+    """HBM traffic per step from rocprofv3 PMC counters, measured now: this script run twice as a child (1 timed + 1 warm-up step, no
+    extras) under `rocprofv3 --pmc FETCH_SIZE --kernel-trace` and `--pmc WRITE_SIZE --kernel-trace` -- the collection
+    MI355X_MICROARCH.md prescribes (separate passes; FETCH_SIZE doubled on gfx950), the same recipe as tools/pmc_traffic.sh.
+    Returns {"conv": bytes, "phase": bytes, "winograd_transforms": bytes, "seconds": s} or {"error": "..."}; never raises."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    t0 = time.time()
+    exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if not exe:
+        return {"error": "rocprofv3 not found"}
+    steps, warm = 1, 1
+    nsteps = steps + warm + 2          # + the two single-stream steps of the child's roofline leg
+    groups = {"conv": ("conv_mfma_kernel", "wino_fused_kernel"), "winograd_transforms": ("wino_in", "wino_out"),
+              "phase": ("pyramid_frame_kernel", "pyramid_kernel", "phase_window2_kernel")}
+    tot = {g: {} for g in groups}
+    tmp = tempfile.mkdtemp(prefix="mm_pmc_", dir="/tmp")
+    try:
+        env = dict(os.environ, TMPDIR="/tmp")
+        for c in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = os.path.join(tmp, c)
+            cmd = [exe, "--pmc", c, "--kernel-trace", "--output-format", "csv", "-d", d, "-o", "out", "--", sys.executable,
+                   os.path.abspath(__file__), "--steps", str(steps), "--warmup", str(warm), "--clips", str(per_step), "--lanes", str(args.lanes),
+                   "--no-cpu-baseline", "--no-extra", "--no-live-traffic"]
+            r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=240)
+            files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+            if r.returncode != 0 or not files:
+                return {"error": "rocprofv3 --pmc %s: rc %d, %d counter files" % (c, r.returncode, len(files))}
+            with open(files[0]) as f:
+                for row in csv.DictReader(f):
+                    if row.get("Counter_Name") != c:
+                        continue
+                    for g, pats in groups.items():
+                        if any(p_ in row["Kernel_Name"] for p_ in pats):
+                            tot[g][c] = tot[g].get(c, 0.0) + float(row["Counter_Value"])
+        out = {}
+        for g in groups:
+            if "FETCH_SIZE" not in tot[g] or "WRITE_SIZE" not in tot[g]:
+                return {"error": "no %s kernels in the counter files" % g}
+            out[g] = (tot[g]["FETCH_SIZE"] * 1024 * 2 + tot[g]["WRITE_SIZE"] * 1024) / nsteps
+        out["seconds"] = time.time() - t0
+        return out
+    except Exception as e:      # noqa: BLE001 -- a profiler problem must never take the bench line down
+        return {"error": "%s: %s" % (type(e).__name__, e)}
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
 def kernel_source_hash():
     """sha256 over the HIP/C++ sources + headers: PMC traffic summaries under profiles/ record the hash of the kernels
     they were measured on, and are only quoted when it still matches (they cannot be re-measured live: PMC counters need
@@ -353,6 +404,8 @@ def parse_args(argv=None):
                     help="distinct synthetic clip contents (clip id mod this); default min(total, 2 x clips)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the direct-form / multi-snippet legs (extra)")
+    ap.add_argument("--no-live-traffic", action="store_true",
+                    help="do not measure roofline.traffic live (two child runs under rocprofv3 --pmc, ~1 min); quote the committed PMC summary")
     ap.add_argument("--extra-steps", type=int, default=5)
     ap.add_argument("--backend", default=None, help="torch.distributed backend for N>1 (default nccl = RCCL on a GPU host; "
                     "gloo only for plumbing tests, e.g. two ranks on one GPU with --same-device)")
@@ -621,6 +674,20 @@ def run_rank(args):
 
     traffic, traffic_file = committed_traffic("conv")
     ptraffic, ptraffic_file = committed_traffic("phase")
+    # (round 5) ... and measured LIVE when this is the default single-GPU run and rocprofv3 is on the box: two child runs of this script
+    # under `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` (separate passes, --kernel-trace only, as MI355X_MICROARCH.md prescribes), so
+    # that the driver's line shows a traffic regression by itself; any failure leaves the committed figures in place
+    live_traffic = None
+    if rank == 0 and world == 1 and not args.no_extra and not args.no_live_traffic:
+        live_traffic = measure_live_traffic(args, per_step)
+    live_note = None
+    if live_traffic and live_traffic.get("conv"):
+        live_note = ("HBM bytes per step over all conv launches, rocprofv3 PMC (2*FETCH_SIZE + WRITE_SIZE)*1024, measured LIVE by this run "
+                     "(two child runs of bench.py under rocprofv3, %.0f s); committed summary for the same sources: %s"
+                     % (live_traffic["seconds"], ("%.4g bytes (profiles/%s)" % (traffic, traffic_file)) if traffic else "none"))
+        traffic, traffic_file = live_traffic["conv"], "live"
+        if live_traffic.get("phase"):
+            ptraffic, ptraffic_file = live_traffic["phase"], "live"
 
     def mixed_roofline():
         """Sum over the launches of this step of max(FLOPs / MFMA peak, HBM bytes / HBM peak) against the sum of their measured
@@ -663,8 +730,10 @@ def run_rank(args):
         "bound": "mfma", "kernel": "conv_mfma_kernel (fp32 implicit-GEMM conv/GEMM engine, all %d launches of one step)" % launches[0],
         "achieved": conv_tflops, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
         "frac": conv_tflops / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic,
-        "traffic_note": ("HBM bytes per step over all conv launches, rocprofv3 PMC (2*FETCH_SIZE + WRITE_SIZE)*1024, from "
-                         "profiles/%s (same kernel sources, not live)" % traffic_file) if traffic else
+        "traffic_note": live_note if live_note else
+                        ("HBM bytes per step over all conv launches, rocprofv3 PMC (2*FETCH_SIZE + WRITE_SIZE)*1024, from "
+                         "profiles/%s (same kernel sources, not live%s)" % (traffic_file, "; live measurement failed: " + live_traffic["error"]
+                                                                         if live_traffic and live_traffic.get("error") else "")) if traffic else
                         "no PMC summary under profiles/ for these kernel sources (hash %s)" % kernel_source_hash(),
         "flops_per_step": work_[0], "ms_per_step": ms[0], "launches_per_step": int(launches[0]),
         "note": "flops = executed on the matrix cores; with Winograd F(4x4,3x3) (or F(2x2,3x3)) on the stride-1 3x3 layers of conv2_x..conv5_x "
@@ -680,7 +749,9 @@ def run_rank(args):
         "mixed_frac": mixed["mixed_frac"] if mixed else None,
         "mixed": mixed if mixed else {"note": mixed_note},
         "winograd_transforms": {"ms_per_step": ms[3], "bytes_per_step": work_[3], "launches_per_step": int(launches[3]),
-                                "GB_per_s": (work_[3] / (ms[3] * 1e-3) / 1e9) if ms[3] > 0 else None}}
+                                "GB_per_s": (work_[3] / (ms[3] * 1e-3) / 1e9) if ms[3] > 0 else None,
+                                "pmc_bytes_per_step_live": live_traffic.get("winograd_transforms") if live_traffic else None},
+        "traffic_source": "live" if live_note else ("committed" if traffic else None)}
     # both floors of the phase stage: HBM (algorithmic bytes at 8 TB/s) and the matrix pipes (pyramid_frame_kernel: 4 344
     # v_mfma_f32_16x16x4_f32 = 8.9 MFLOP per frame) -- the MFMA floor is the higher one
     ph_floor_hbm = (work_[1] + work_[2]) / (PEAK_HBM_GBS * 1e9) * 1e3
