@@ -73,7 +73,7 @@ def measure_live_traffic(args, per_step):
             cmd = [exe, "--pmc", c, "--kernel-trace", "--output-format", "csv", "-d", d, "-o", "out", "--", sys.executable,
                    os.path.abspath(__file__), "--steps", str(steps), "--warmup", str(warm), "--clips", str(per_step), "--lanes", str(args.lanes),
                    "--no-cpu-baseline", "--no-extra", "--no-live-traffic"]
-            r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=240)
+            r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=90)
             files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
             if r.returncode != 0 or not files:
                 return {"error": "rocprofv3 --pmc %s: rc %d, %d counter files" % (c, r.returncode, len(files))}
