@@ -4,7 +4,9 @@ import ctypes
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libmimamo_hip.so")
+# MM_LIB_PATH: another build of the same library (tools/ A/B variants and -DMM_MEASURE builds under tools/_ab/, so that no measurement script
+# ever copies a variant over the shipped file); unset everywhere else.  The loader says so on stderr -- never silently
+LIB_PATH = os.environ.get("MM_LIB_PATH") or os.path.join(HERE, "libmimamo_hip.so")
 
 MM_OK = 0
 MM_ERR_INVALID_ARG = -1
@@ -90,6 +92,9 @@ def lib():
         # HIP runtime instance (same SONAME -> the loader reuses it).  Loading ours first would pull in
         # /opt/rocm's runtime and leave torch on a mixed stack ("no device").
         import torch  # noqa: F401
+        if os.environ.get("MM_LIB_PATH"):
+            import sys
+            sys.stderr.write("mimamo_net_amd: loading the library variant MM_LIB_PATH=%s\n" % LIB_PATH)
         l = ctypes.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(l, name)  # AttributeError if the .so does not export a declared symbol

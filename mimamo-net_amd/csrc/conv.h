@@ -78,8 +78,12 @@ int wino_gemm_output_fused(const float* V, const float* U, const float* bias, fl
 // The same kernel with the residual block's 1x1 increase conv inside its epilogue -- (Cout, C2) == (64, 256): conv2_x blocks 2, 3, or
 // (128, 512): conv3_x blocks 2-4 (eight-wave workgroup):
 // out [B,H,W,C2] = relu( W2 relu(conv3x3(x) + bias) + bias2 + res ); the Cout-channel tensor in between never reaches HBM.
+// next_w / next_bias / next_out (round 6, (64, 256) only; null = off): the NEXT block's 1x1 reduce conv, [64][C2] BN-folded + ReLU, applied to `out`
+// before it leaves the CU: next_out [B,H,W,64] = relu(next_w out + next_bias) -- that block's 256 -> 64 launch and its re-read of `out` disappear.
+// shape: 0 = default, 8 = eight-wave workgroups without next_* (A/B of the shape), 2 = -DMM_MEASURE cost proxy (wrong results)
 int wino_gemm_output_fused_inc(const float* V, const float* U, const float* bias, const float* W2, const float* bias2, const float* res,
-                               float* out, int B, int H, int W, int Cin, int Cout, int C2, int relu, hipStream_t s, int generic_loop = 0);
+                               float* out, int B, int H, int W, int Cin, int Cout, int C2, int relu, hipStream_t s, int generic_loop = 0,
+                               const float* next_w = nullptr, const float* next_bias = nullptr, float* next_out = nullptr, int shape = 0);
 bool wino_fused_inc_supported(int64_t ntile, int Cin, int Cout, int C2);
 // ... and with increase conv + stride-1 projection shortcut as one contraction over [relu(conv3x3) ; x] (conv2_x block 1): W2 [C2][128]
 int wino_gemm_output_fused_incproj(const float* V, const float* U, const float* bias, const float* W2, const float* bias2, const float* x,

@@ -226,9 +226,12 @@ static int g_wino_fused_shape = 0;       // workgroup shape of the fused kernel,
 // anything is launched) when the shape is not the one wino_fused.hip's INC instantiation takes.
 // inc_two_src: `inc` is a make_layer_dual layer (K = L.cout + L.cout: increase | stride-1 projection) and inc_res the block input x
 // [B,H,W,L.cout] -- inc_out = relu(inc([relu(L(in)); x])), no residual.
+// next / next_out (optional, with inc on the (64, 256) shape only): the NEXT block's stride-1 1x1 reduce layer (inc->cout -> 64) run inside the
+// same kernel on the block output -- next_out [B,H,W,64] = relu(next(inc_out)); inc_shape: workgroup variant of that kernel (measurement knob)
 static int run_layer_wino(const Layer& L, const float* in, int B, int H, int W, float* out, float* V, float* M, int m, hipStream_t s,
                           const Layer* inc = nullptr, const float* inc_res = nullptr, float* inc_out = nullptr, bool inc_two_src = false,
-                          int x3 = 0, int generic_loop = 0, int no_sched = 0) {
+                          int x3 = 0, int generic_loop = 0, int no_sched = 0, const Layer* next = nullptr, float* next_out = nullptr,
+                          int inc_shape = 0) {
     const int mt = m == 5 ? 4 : m;
     const int TH = (H + mt - 1) / mt, TW = (W + mt - 1) / mt, npos = (mt + 2) * (mt + 2);
     const int64_t ntile = (int64_t)B * TH * TW;
@@ -243,6 +246,9 @@ static int run_layer_wino(const Layer& L, const float* in, int B, int H, int W, 
     if (inc && !(fused && inc->k == 1 && inc->stride == 1 && inc->Kpad == (inc_two_src ? 2 : 1) * L.cout && inc->korder == 0 && inc->relu &&
                  !inc->ps && (!inc_two_src || L.cout == 64) && wino_fused_inc_supported(ntile, wc, L.cout, inc->cout)))
         return MM_ERR_UNSUPPORTED;
+    if (next && !(inc && !inc_two_src && L.cout == 64 && inc->cout == 256 && next_out && next->k == 1 && next->stride == 1 && next->pad == 0 &&
+                  next->cin_p == 256 && next->Kpad == 256 && next->cout == 64 && next->korder == 0 && next->relu && !next->ps && next->bias))
+        return MM_ERR_UNSUPPORTED;
     int rc = wino_input_transform(in, V, B, H, W, wc, m, s, L.cin_p);
     if (rc != MM_OK) return rc;
     if (inc && inc_two_src)
@@ -250,7 +256,7 @@ static int run_layer_wino(const Layer& L, const float* in, int B, int H, int W, 
                                               L.relu, s, generic_loop);
     if (inc)
         return wino_gemm_output_fused_inc(V, L.wino_u4, L.bias, inc->w, inc->bias, inc_res, inc_out, B, H, W, wc, L.cout, inc->cout,
-                                          L.relu, s, generic_loop);
+                                          L.relu, s, generic_loop, next ? next->w : nullptr, next ? next->bias : nullptr, next_out, inc_shape);
     if (fused) {
         rc = wino_gemm_output_fused(V, L.wino_u4, L.bias, out, B, H, W, wc, L.cout, L.relu, g_wino_fused_shape, s, generic_loop);
         if (rc != MM_ERR_UNSUPPORTED) return rc;
@@ -309,6 +315,10 @@ struct mm_resnet50 {
     int wf_generic;// MM_WF_KSL=0 at create time: the fused Winograd kernels' runtime-scheduled main loop (the parity twin of round 5's compile-time one)
     int precision; // 0 (default): every contraction on the fp32 matrix pipes; 1: 1x1 layers with K >= 512 through the three-way bf16 split
                    // (mm_resnet50_set_precision; bench.py's extra.bf16x3 -- never the headline)
+    int fuse_next; // round 6: the fused conv2_x kernel of a block also runs the NEXT block's 256 -> 64 reduce conv on its output (wino_fused.hip NEXT): 0
+                   // (default) = off, 1 (MM_FUSE_NEXT=1) = conv2_x block 2 -> block 3.  Built, parity-tested, measured SLOWER (+0.3 ms per step,
+                   // profiles/r06_ab_next_reduce.txt: the kernel's time is MFMA time + memory time, added matrix work hides under nothing)
+    int inc_shape; // workgroup variant of the conv2_x fused kernel (measurement knob MM_INC1_SHAPE: 8 = eight waves without NEXT)
     int fuse_inc;  // 3x3 + increase conv (+ residual | + projection) in ONE kernel (wino_fused.hip INC): 0 = never (the parity twin), 1 = conv2_x
                    // blocks 2-3, 2 = also conv2_x block 1 (increase | projection over two K sources), 3 (default) = also conv3_x blocks 2-4
     int device;
@@ -439,6 +449,10 @@ int mm_resnet50_create(mm_resnet50_t** out, const float* blob, int64_t n_floats,
         const char* fi = getenv("MM_FUSE_INC");    // measurement knob: 0 = 3x3 and increase conv as separate launches (the parity twin)
         // 1 = conv2_x blocks 2, 3 only; 2 = also block 1 (increase | projection over two K sources); 3 = also conv3_x blocks 2-4
         h->fuse_inc = fi ? atoi(fi) : 3;
+        const char* fn = getenv("MM_FUSE_NEXT");   // measurement knob: 1 = the next block's reduce conv inside the fused conv2_x kernel (measured slower)
+        h->fuse_next = fn ? atoi(fn) : 0;
+        const char* is = getenv("MM_INC1_SHAPE");  // measurement knob: 8 = the conv2_x fused kernel as eight-wave workgroups (without NEXT)
+        h->inc_shape = is ? atoi(is) : 0;
     }
     auto conv_bn = [&](Layer& L, int cout, int cin, int k, int stride, int pad, int relu) {
         const float* w = p;
@@ -583,7 +597,10 @@ int mm_resnet50_forward(mm_resnet50_t* h, const float* images, int nchw, int64_t
     int xi = 1;  // index of the buffer holding the block input
     int C = 64;
     const int x3 = h->precision == 1, ns = h->no_sched;
-    for (const Bottleneck& Bk : h->blocks) {
+    bool reduce_done = false;   // the previous block's fused kernel has already written this block's reduce output into y1 (fuse_next)
+    for (size_t bi = 0; bi < h->blocks.size(); ++bi) {
+        const Bottleneck& Bk = h->blocks[bi];
+        const Bottleneck* Nx = bi + 1 < h->blocks.size() ? &h->blocks[bi + 1] : nullptr;
         float* x = big[xi];
         float* sc = big[(xi + 1) % 3];
         float* o = big[(xi + 2) % 3];
@@ -595,8 +612,9 @@ int mm_resnet50_forward(mm_resnet50_t* h, const float* images, int nchw, int64_t
             if (rc != MM_OK) return rc;
             resid = sc;
         }
-        if (pooled_reduce && &Bk == &h->blocks.front()) {
-            H1 = H; W1 = W;                        // y1 was written by the pool kernel
+        if ((pooled_reduce && bi == 0) || reduce_done) {
+            H1 = H; W1 = W;                        // y1 was written by the pool kernel / by the previous block's fused kernel
+            reduce_done = false;
         } else {
             rc = run_layer(Bk.reduce, x, B, H, W, C, 0, y1, Bk.reduce.cout, 0, nullptr, 0, s, &H1, &W1, x3, ns);
             if (rc != MM_OK) return rc;
@@ -612,7 +630,17 @@ int mm_resnet50_forward(mm_resnet50_t* h, const float* images, int nchw, int64_t
             if (wm_ == 5 && h->fuse_inc && !Bk.has_proj && (Bk.conv3.cout == 64 || h->fuse_inc >= 3)) {
                 // conv2_x blocks 2, 3 (Cin = Cout = 64 -> 256) and, with MM_FUSE_INC >= 3, conv3_x blocks 2-4 (128 -> 512): 3x3 +
                 // increase + residual + ReLU in one kernel
-                rc = run_layer_wino(Bk.conv3, y1, B, H1, W1, nullptr, wv, nullptr, 5, s, &Bk.increase, x, o, false, 0, h->wf_generic);
+                // ... and (fuse_next) the NEXT block's stride-1 256 -> 64 reduce conv on the block output, written to y1 -- dead once the input transform
+                // has read it (same stream): that block then starts at its 3x3 layer
+                const bool nx = h->fuse_next && Bk.conv3.cout == 64 && Nx && !Nx->has_proj && Nx->reduce.stride == 1;
+                if (nx) {
+                    rc = run_layer_wino(Bk.conv3, y1, B, H1, W1, nullptr, wv, nullptr, 5, s, &Bk.increase, x, o, false, 0, h->wf_generic, 0, &Nx->reduce, y1,
+                                        h->inc_shape);
+                    reduce_done = rc == MM_OK;
+                }
+                if (!nx || rc == MM_ERR_UNSUPPORTED)
+                    rc = run_layer_wino(Bk.conv3, y1, B, H1, W1, nullptr, wv, nullptr, 5, s, &Bk.increase, x, o, false, 0, h->wf_generic, 0, nullptr, nullptr,
+                                        h->inc_shape);
                 inc_done = rc == MM_OK;
             } else if (wm_ == 5 && h->fuse_inc >= 2 && dual && Bk.proj_stride == 1 && C == Bk.conv3.cout && H1 == H && W1 == W) {
                 // conv2_x block 1: 3x3 + (increase | projection of the block input) + ReLU in one kernel

@@ -21,7 +21,7 @@
 // The reference computes these layers with torch's direct fp32 conv (third-party ResNet50, api/resnet50_extractor.py:74-83);
 // parity is checked against the oracle's direct convolution.
 //
-// mm-hipcc-flags: -mllvm -amdgpu-promote-alloca-to-vector-limit=4096
+// mm-hipcc-flags: -mllvm -amdgpu-promote-alloca-to-vector-limit=4096 -mllvm -pragma-unroll-threshold=131072
 // (build.py passes this to hipcc for this file.  The eight-wave INC 3 instantiation has more per-thread arrays than the backend's
 //  default promote-to-vector budget for a 512-thread workgroup: without it half of the 128-register Y array stays in scratch --
 //  272 bytes per lane, element-wise scratch stores in the transform -- although only 190 VGPRs are in use.  The other
@@ -47,6 +47,11 @@ struct WinoFusedParams {
     const float* bias2;  // [C2]
     const float* res;    // INC 1: residual, NHWC [B][H][W][C2].  INC 2: the block input x, NHWC [B][H][W][Cout] -- the second K source
     int C2;              // 256
+    // NEXT instantiation only (round 6): the NEXT residual block's 1x1 reduce conv (C2 -> 64, BN folded, ReLU) applied to the block output
+    // this kernel has just computed -- pointwise, no halo: out3 [B][H][W][64] = relu(W3 out + bias3) beside `out`
+    const float* w3;     // [64][C2]
+    const float* bias3;  // [64]
+    float* out3;         // NHWC [B][H][W][64]
     int generic_loop;    // 1: the runtime-scheduled main loop whatever K is (the parity twin of the compile-time-scheduled one)
     int ablate;          // -DMM_MEASURE builds only (results wrong by construction): bit 0 = every workgroup reads the V rows of the first
                          // 1 024 tiles (L2-resident: the kernel without its V traffic), bit 1 = residual rows from the first 4 096 pixels,
@@ -81,7 +86,7 @@ static constexpr float kAtHost[4][6] = {{1, 1, 1, 1, 1, 0}, {0, 1, -1, 2, -2, 0}
 // folds into the ds_read_b128 offset field and into the M0 immediates of the DMA, and the k offset rides in the buffer instruction's scalar
 // offset: no VALU instruction is left in a slab besides the MFMAs and the output transform's updates.  Same operations on the same values in
 // the same order: bit-identical results (the KSL = 0 loop stays as the twin for any other K).
-template <int NBUF, int WGM, int INC = 0, int WGN = 2, int KSL = 0>
+template <int NBUF, int WGM, int INC = 0, int WGN = 2, int KSL = 0, int NEXT = 0>
 __global__ void __launch_bounds__(WGM * WGN * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
 wino_fused_kernel(const WinoFusedParams p) {
     // WGM = 4: eight waves, 64 tiles x 64 channels, one workgroup per CU; WGM = 2: four waves, 32 tiles x 64 channels, two
@@ -863,8 +868,16 @@ wino_fused_kernel(const WinoFusedParams p) {
         // Wave (wm, wn) then produces channels [128 wn, 128 wn + 128) of its 16 tiles: lane (l16, lg) ends up with 4 consecutive
         // output channels of tile l16 per 16-row block -> 16-byte stores and residual loads, 64 contiguous bytes per tile per
         // instruction, no transpose.
-        static_assert(WGM == 2 && NBUF == 3, "INC is built for the four-wave workgroup");
+        // NEXT (round 6): ... and a THIRD GEMM chained from those accumulators -- again the B operand of a 16x16x4 MFMA as they are --
+        // against the next block's 64 x 256 reduce matrix W3 (64 KB, 1 KB rows, same XOR swizzle): each wave contracts its own 128
+        // channels into partial sums D for all 64 outputs (128 MFMAs per position, as many as the increase conv), hands the half the
+        // partner finishes over through the exchange area, adds the partner's half to its own, + bias3, ReLU, 16-byte stores of the
+        // 64-channel tensor.  Both matrices + exchange = 145 KB: an EIGHT-wave workgroup (WGM = 4: 64 tiles x 64 channels, one per
+        // CU, still two waves per SIMD); the four-wave NEXT instantiation exists in -DMM_MEASURE builds only and reads its "W3"
+        // fragments from the W2 area (results wrong by construction: the cost of the third GEMM with two workgroups per CU kept).
+        static_assert((WGM == 2 || WGM == 4) && WGN == 2 && NBUF == 3, "INC 1 is built for the four- and the eight-wave workgroup");
         constexpr int W2_FLOATS = 256 * KS;
+        constexpr bool W3_REAL = NEXT && WGM == 4;                        // W3 has its own 64 KB of LDS
         {
             const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.w2), 0, (unsigned)(W2_FLOATS * 4), 0x00020000);
 #pragma unroll
@@ -874,8 +887,22 @@ wino_fused_kernel(const WinoFusedParams p) {
                 dma1(rw, voff, lds0 + (unsigned)((it * NW + wave) * 1024));
             }
         }
-        float* xb = lds + W2_FLOATS;                                   // [4 waves][2 channel blocks][4 lg][16 l16] float4
+        float* xb = lds + W2_FLOATS;                                   // [NW waves][2 channel blocks][4 lg][16 l16] float4
         const int x_own = (wave * 8 + lg) * 64 + l16 * 4, x_par = ((wave ^ 1) * 8 + lg) * 64 + l16 * 4;
+        // bias2 -> LDS behind the exchange area (1 KB): read back per block as the accumulators' initial value
+        float* b2s = xb + NW * 512;
+        float* b3s = b2s + 256;                                        // NEXT: bias3 [64]
+        float* w3s = b3s + 64;                                         // NEXT: [64][256] floats, quad q of row r in slot q ^ (r & 15)
+        if constexpr (W3_REAL) {
+            const __amdgpu_buffer_rsrc_t rw3 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.w3), 0, (unsigned)(64 * 256 * 4), 0x00020000);
+            const unsigned w3b = lds0 + (unsigned)(W2_FLOATS + NW * 512 + 256 + 64) * 4u;
+#pragma unroll
+            for (int it = 0; it < 64 / NW; ++it) {
+                const int row = it * NW + wave;                            // one 1 KB row per wave instruction
+                const unsigned voff = (unsigned)(row * 256 + ((lane ^ (row & 15)) << 2)) * 4u;
+                dma1(rw3, voff, w3b + (unsigned)(row * 1024));
+            }
+        }
         f32x4v b1[2];
 #pragma unroll
         for (int cb = 0; cb < 2; ++cb) {
@@ -899,10 +926,21 @@ wino_fused_kernel(const WinoFusedParams p) {
             const int qd = ((sidx < 2 ? wn : 1 - wn) * 8 + (sidx & 1) * 4 + lg) ^ l16;
             wa[sidx] = (wn * 128 + l16) * KS + (qd << 2);
         }
-        // bias2 -> LDS behind the exchange area (1 KB): read back per block as the accumulators' initial value
-        float* b2s = xb + 2048;
-        b2s[tid] = p.bias2[tid];                                          // 256 threads, C2 == 256
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");   // W2 and bias2 landed
+        // NEXT: W3 fragment of output block nb, half h, 16-channel block j: row 16 nb + l16, k-quad (32 wn + 16 h + 4 j + lg) ^ l16 (the XOR only
+        // touches the low four bits of the quad index: one lane offset per j; nb and h fold into the instruction's offset field)
+        int w3a[4] = {0, 0, 0, 0};
+        float* o3base = nullptr;
+        if constexpr (NEXT) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if constexpr (W3_REAL) w3a[j] = l16 * 256 + (((32 * wn + 4 * j + lg) ^ l16) << 2);
+                else w3a[j] = l16 * KS + (((4 * j + lg) ^ l16) << 2);    // measurement proxy: valid, conflict-free addresses inside W2
+            }
+            o3base = p.out3 + pix0 * 64 + 32 * wn + 4 * lg;
+        }
+        if (tid < 256) b2s[tid] = p.bias2[tid];                          // C2 == 256
+        if (NEXT && tid < 64) b3s[tid] = p.bias3[tid];
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");   // W2 (W3) and bias2 landed
         // 32 half-position steps (position = (pp, qq), half = 64 of this wave's 128 output channels).  The residual rows of step
         // s + 1 are requested before the MFMAs of step s (their HBM latency runs under 64 MFMAs and, across a position change,
         // under the exchange barriers).
@@ -922,18 +960,32 @@ wino_fused_kernel(const WinoFusedParams p) {
         // (round 5) the residual rows of up to MM_INC1_RES_DEPTH steps ahead are in flight: the kernel's time is the SUM of its MFMA time and
         // its memory time (profiles/r05_inc1_ablation.txt: without residual loads / stores / operand DMA -1.0 / -1.5 / -1.1 ms of 7.8, without 64 %
         // of the MFMAs -0.65) -- eight waves per CU with one step (4 KB per wave) of loads in flight do not cover the HBM latency.  The depth
-        // grows as the Y registers of finished positions die (8 per position): 1 for positions 0-1, 2 for 2-3, 3 from position 4 on.
+        // grows as the Y registers of finished positions die (8 per position): 1 for positions 0-1, 2 for 2-3, 3 from position 4 on
+        // (NEXT, which also carries the 16 partial-sum registers D: two positions later).
 #ifndef MM_INC1_RES_DEPTH
 #define MM_INC1_RES_DEPTH 3
 #endif
         auto res_ahead = [](int step) {      // last step whose residual rows have been requested once step `step` has issued its loads
             if (step < 0) return 0;
-            int d = 1 + (step >> 2);
+            int d = 1 + ((NEXT ? (step < 4 ? 0 : step - 4) : step) >> 2);
             d = d > MM_INC1_RES_DEPTH ? MM_INC1_RES_DEPTH : d;
             const int t = step + d;
             return t > 31 ? 31 : t;
         };
-        f32x4v rs[4][4], Pr[2];
+        if constexpr (NEXT) {      // bias + ReLU of all 16 positions up front: the 8 bias registers are not carried through the steps
+#pragma unroll
+            for (int pp = 0; pp < 4; ++pp)
+#pragma unroll
+                for (int qq = 0; qq < 4; ++qq)
+#pragma unroll
+                    for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const float v = Y[pp][qq][cb][e] + b1[cb][e];
+                            Y[pp][qq][cb][e] = p.relu ? fmaxf(v, 0.f) : v;
+                        }
+        }
+        f32x4v rs[4][4], Pr[2], D[4];
 #ifdef MM_MEASURE
         const int abl = p.ablate;
 #else
@@ -948,6 +1000,7 @@ wino_fused_kernel(const WinoFusedParams p) {
         for (int step = 0; step < 32; ++step) {
             const int pp = step >> 3, qq = (step >> 1) & 3, h = step & 1;
             if (h == 0) {
+                if constexpr (!NEXT) {
 #pragma unroll
                 for (int cb = 0; cb < 2; ++cb)
 #pragma unroll
@@ -955,12 +1008,16 @@ wino_fused_kernel(const WinoFusedParams p) {
                         const float v = Y[pp][qq][cb][e] + b1[cb][e];
                         Y[pp][qq][cb][e] = p.relu ? fmaxf(v, 0.f) : v;
                     }
-                if (step && !(abl & 32)) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // the previous position's copies have been read
+                }
+                // the previous position's copies have been read.  (NEXT: no barrier here -- a wave's area is last read BY ITSELF, the partial
+                // sums its partner left there, before it writes the next position's copy: program order)
+                if (!NEXT && step && !(abl & 32)) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 #pragma unroll
                 for (int cb = 0; cb < 2; ++cb) *reinterpret_cast<f32x4v*>(xb + x_own + cb * 256) = Y[pp][qq][cb];
                 if (!(abl & 32)) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 #pragma unroll
                 for (int cb = 0; cb < 2; ++cb) Pr[cb] = *reinterpret_cast<const f32x4v*>(xb + x_par + cb * 256);
+                if constexpr (NEXT) D[0] = D[1] = D[2] = D[3] = f32x4v{0.f, 0.f, 0.f, 0.f};
             }
             if (!(abl & 8)) {
 #pragma unroll
@@ -991,10 +1048,54 @@ wino_fused_kernel(const WinoFusedParams p) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) acc[j][e] = fmaxf(acc[j][e], 0.f);
             }
-            if (tok && 4 * ty + pp < p.H && 4 * tx + qq < p.W && !(abl & 16)) {
+            const bool pix_ok = tok && 4 * ty + pp < p.H && 4 * tx + qq < p.W;
+            if (pix_ok && !(abl & 16)) {
                 float* op = obase + ((int64_t)pp * p.W + qq) * p.C2 + h * 64;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) __builtin_nontemporal_store(acc[j], reinterpret_cast<f32x4v*>(op + j * 16));
+            }
+            if constexpr (NEXT) {
+                // third GEMM: D[nb] += W3[16 nb + l16][these 64 channels] * x[these 64 channels][tile l16]; x = acc as it stands
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float4 w4[4];
+#pragma unroll
+                    for (int nb = 0; nb < 4; ++nb)
+                        w4[nb] = *reinterpret_cast<const float4*>((W3_REAL ? w3s + nb * 16 * 256 + 16 * h * 4 : lds + (nb * 16 + h * 64) * KS) + w3a[j]);
+#pragma unroll
+                    for (int nb = 0; nb < 4; ++nb) D[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(w4[nb].x, acc[j][0], D[nb], 0, 0, 0);
+#pragma unroll
+                    for (int nb = 0; nb < 4; ++nb) D[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(w4[nb].y, acc[j][1], D[nb], 0, 0, 0);
+#pragma unroll
+                    for (int nb = 0; nb < 4; ++nb) D[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(w4[nb].z, acc[j][2], D[nb], 0, 0, 0);
+#pragma unroll
+                    for (int nb = 0; nb < 4; ++nb) D[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(w4[nb].w, acc[j][3], D[nb], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);      // one block's four fragments at a time (hoisted, the reads of all four blocks spill)
+                }
+                if (h == 1) {
+                    // wave wn finishes output blocks 2 wn, 2 wn + 1: the other two go to the partner through ITS area (which this wave has finished
+                    // reading the partner's Y copy from), the partner's arrive in this wave's own
+                    f32x4v give[2], keep[2];
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const float lo = D[i][e], hi = D[2 + i][e];
+                            give[i][e] = wn ? lo : hi;
+                            keep[i][e] = wn ? hi : lo;
+                        }
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) *reinterpret_cast<f32x4v*>(xb + x_par + i * 256) = give[i];
+                    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) {
+                        const f32x4v got = *reinterpret_cast<const f32x4v*>(xb + x_own + i * 256);
+                        f32x4v d = keep[i] + got + *reinterpret_cast<const f32x4v*>(b3s + 32 * wn + 16 * i + 4 * lg);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) d[e] = fmaxf(d[e], 0.f);
+                        if (pix_ok && !(abl & 16)) __builtin_nontemporal_store(d, reinterpret_cast<f32x4v*>(o3base + ((int64_t)pp * p.W + qq) * 64 + i * 16));
+                    }
+                }
             }
         }
         return;
@@ -1049,19 +1150,21 @@ wino_fused_kernel(const WinoFusedParams p) {
     }
 }
 
-template <int NBUF, int WGM, int INC = 0, int WGN = 2, int KSL = 0>
+template <int NBUF, int WGM, int INC = 0, int WGN = 2, int KSL = 0, int NEXT = 0>
 static int launch_fused_k(WinoFusedParams p, hipStream_t s) {
     constexpr int BM = 16 * WGM, BN = 32 * WGN;
     // INC: the increase matrix (64 KB) + exchange area (8 KB) take the dead operand ring, bias2 (1 KB) sits behind it: 73 KB, two
-    // workgroups per CU still fit the 160 KB
-    constexpr int LDS_BYTES = (INC == 1 || INC == 2) ? (256 * 64 + 2048 + 256) * 4
-                              : INC == 3 ? inc3_lds_bytes(NBUF * (BM + BN) * 64 * 4) : NBUF * (BM + BN) * 64 * 4;
-    static_assert(LDS_BYTES >= NBUF * (BM + BN) * 64 * 4, "the ring must fit too");
+    // workgroups per CU still fit the 160 KB.  Eight waves (WGM = 4): 16 KB exchange area, and with NEXT the 64 KB reduce matrix: 145 KB
+    constexpr int RING_BYTES = NBUF * (BM + BN) * 64 * 4;
+    constexpr int EPI_BYTES = (INC == 1 || INC == 2) ? (256 * 64 + WGM * WGN * 512 + 256 + (NEXT ? 64 : 0) + (NEXT && WGM == 4 ? 64 * 256 : 0)) * 4 : 0;
+    constexpr int LDS_BYTES = (INC == 1 || INC == 2) ? (EPI_BYTES > RING_BYTES ? EPI_BYTES : RING_BYTES)
+                              : INC == 3 ? inc3_lds_bytes(RING_BYTES) : RING_BYTES;
+    static_assert(LDS_BYTES >= RING_BYTES && LDS_BYTES <= 160 * 1024, "the ring must fit too");
     static bool attr_set[16] = {};
     int dev = 0;
     (void)hipGetDevice(&dev);
     if (dev >= 0 && dev < 16 && !attr_set[dev]) {
-        MM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(wino_fused_kernel<NBUF, WGM, INC, WGN, KSL>), hipFuncAttributeMaxDynamicSharedMemorySize,
+        MM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(wino_fused_kernel<NBUF, WGM, INC, WGN, KSL, NEXT>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                    LDS_BYTES));
         attr_set[dev] = true;
     }
@@ -1073,7 +1176,7 @@ static int launch_fused_k(WinoFusedParams p, hipStream_t s) {
     const int lds_bytes = LDS_BYTES + (INC ? lds_pad : 0);
     p.ablate = INC ? ablate : 0;
     if (INC && lds_pad)
-        MM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(wino_fused_kernel<NBUF, WGM, INC, WGN, KSL>), hipFuncAttributeMaxDynamicSharedMemorySize,
+        MM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(wino_fused_kernel<NBUF, WGM, INC, WGN, KSL, NEXT>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                    lds_bytes));
 #else
     constexpr int lds_bytes = LDS_BYTES;
@@ -1086,13 +1189,14 @@ static int launch_fused_k(WinoFusedParams p, hipStream_t s) {
     if (blocks <= 0 || blocks > 0x7fffffff) return MM_ERR_INVALID_ARG;
     if (prof_enabled()) {
         char tag[64];
-        snprintf(tag, sizeof(tag), "wino-fused%s M=%d K=%d N=%d t%dx%d b36", INC == 3 ? "+inc512" : INC == 2 ? "+incproj256" : INC ? "+inc256" : "", p.ntile,
-                 p.K, p.Cout, BM, BN);
+        snprintf(tag, sizeof(tag), "wino-fused%s%s M=%d K=%d N=%d t%dx%d b36", INC == 3 ? "+inc512" : INC == 2 ? "+incproj256" : INC ? "+inc256" : "",
+                 NEXT ? "+red64" : "", p.ntile, p.K, p.Cout, BM, BN);
         double fl = 2.0 * 36.0 * (double)p.ntile * (double)p.K * (double)p.Cout;
         if (INC) fl += 2.0 * (double)p.B * p.H * p.W * (double)(INC == 2 ? 2 * p.Cout : p.Cout) * (double)p.C2;
+        if (NEXT) fl += 2.0 * (double)p.B * p.H * p.W * (double)p.C2 * 64.0;
         prof_before(0, fl, s, tag);
     }
-    hipLaunchKernelGGL((wino_fused_kernel<NBUF, WGM, INC, WGN, KSL>), dim3((unsigned)blocks), dim3(WGM * WGN * 64), lds_bytes, s, p);
+    hipLaunchKernelGGL((wino_fused_kernel<NBUF, WGM, INC, WGN, KSL, NEXT>), dim3((unsigned)blocks), dim3(WGM * WGN * 64), lds_bytes, s, p);
     prof_after(0, s);
     MM_LAUNCH_CHECK();
     return MM_OK;
@@ -1100,8 +1204,12 @@ static int launch_fused_k(WinoFusedParams p, hipStream_t s) {
 
 // K = 64 / 128 / 256 (every ResNet50 / PhaseNet layer that comes here) take the compile-time-scheduled loop, any other multiple of 64 -- and
 // every K when the caller asks for the twin (p.generic_loop: MM_WF_KSL=0 at create time, the parity twin) -- the generic one
-template <int NBUF, int WGM, int INC = 0, int WGN = 2>
+template <int NBUF, int WGM, int INC = 0, int WGN = 2, int NEXT = 0>
 static int launch_fused(const WinoFusedParams& p, hipStream_t s) {
+    if constexpr (INC == 1 && (NEXT || WGM == 4)) {      // round 6: the eight-wave conv2_x kernel and its NEXT form exist for K = 64 on the compile-time loop,
+        if (p.K != 64) return MM_ERR_UNSUPPORTED;        // the generic loop as the twin
+        return p.generic_loop ? launch_fused_k<NBUF, WGM, INC, WGN, 0, NEXT>(p, s) : launch_fused_k<NBUF, WGM, INC, WGN, 1, NEXT>(p, s);
+    } else {
     // (the eight-wave conv3_x kernel -- 2 x 4 waves, K = 128 -- takes it with a second set of fragment base registers for ring slot 2, see FAR2)
     if constexpr (NBUF == 3 && WGM == 2 && WGN == 4 && INC == 3) {
         if (!p.generic_loop && p.K == 128) return launch_fused_k<NBUF, WGM, INC, WGN, 2>(p, s);
@@ -1114,6 +1222,7 @@ static int launch_fused(const WinoFusedParams& p, hipStream_t s) {
         }
     }
     return launch_fused_k<NBUF, WGM, INC, WGN, 0>(p, s);
+    }
 }
 
 bool wino_fused_supported(int64_t ntile, int Cin, int Cout) {
@@ -1133,6 +1242,7 @@ int wino_gemm_output_fused(const float* V, const float* U, const float* bias, fl
     p.generic_loop = generic_loop;
     p.V = V; p.U = U; p.bias = bias; p.out = y;
     p.w2 = nullptr; p.bias2 = nullptr; p.res = nullptr; p.C2 = 0;
+    p.w3 = nullptr; p.bias3 = nullptr; p.out3 = nullptr;
     p.TH = (H + 3) / 4; p.TW = (W + 3) / 4;
     const int64_t ntile = (int64_t)B * p.TH * p.TW;
     if (!wino_fused_supported(ntile, Cin, Cout)) return MM_ERR_UNSUPPORTED;
@@ -1147,18 +1257,31 @@ int wino_gemm_output_fused(const float* V, const float* U, const float* bias, fl
 // The 3x3 layer AND the block's increase conv: V, U as above with Cout == 64;  out [B,H,W,C2] = relu( W2 relu(conv3x3 + bias) +
 // bias2 + res ), W2 [C2][64] (BN folded), res NHWC [B,H,W,C2], C2 == 256.  MM_ERR_UNSUPPORTED for any other shape.
 int wino_gemm_output_fused_inc(const float* V, const float* U, const float* bias, const float* W2, const float* bias2, const float* res,
-                               float* out, int B, int H, int W, int Cin, int Cout, int C2, int relu, hipStream_t s, int generic_loop) {
+                               float* out, int B, int H, int W, int Cin, int Cout, int C2, int relu, hipStream_t s, int generic_loop,
+                               const float* next_w, const float* next_bias, float* next_out, int shape) {
     if (!V || !U || !W2 || !bias2 || !res || !out) return MM_ERR_INVALID_ARG;
     WinoFusedParams p;
     p.generic_loop = generic_loop;
     p.V = V; p.U = U; p.bias = bias; p.out = out;
     p.w2 = W2; p.bias2 = bias2; p.res = res; p.C2 = C2;
+    p.w3 = nullptr; p.bias3 = nullptr; p.out3 = nullptr;
     p.TH = (H + 3) / 4; p.TW = (W + 3) / 4;
     const int64_t ntile = (int64_t)B * p.TH * p.TW;
     if (!wino_fused_inc_supported(ntile, Cin, Cout, C2)) return MM_ERR_UNSUPPORTED;
     if (ntile <= 0) return MM_OK;
     p.ntile = (int)ntile; p.K = Cin; p.Cout = Cout; p.B = B; p.H = H; p.W = W; p.relu = relu; p.tiles_n = 0;
-    if (Cout == 128) return launch_fused<3, 2, 3, 4>(p, s);     // conv3_x: 2 x 4 waves, 32 tiles x 128 channels, 128 -> 512
+    if (Cout == 128) return next_w ? MM_ERR_UNSUPPORTED : launch_fused<3, 2, 3, 4>(p, s);     // conv3_x: 2 x 4 waves, 32 tiles x 128 channels, 128 -> 512
+    if (next_w) {
+        // the next block's reduce conv in the same kernel (NEXT): eight-wave workgroups, W2 + W3 in LDS.  shape 2 (-DMM_MEASURE builds only): the
+        // four-wave cost proxy whose third GEMM reads W2's LDS rows -- results wrong by construction
+        if (!next_bias || !next_out || C2 != 256) return MM_ERR_INVALID_ARG;
+        p.w3 = next_w; p.bias3 = next_bias; p.out3 = next_out;
+#ifdef MM_MEASURE
+        if (shape == 2) return launch_fused<3, 2, 1, 2, 1>(p, s);
+#endif
+        return launch_fused<3, 4, 1, 2, 1>(p, s);
+    }
+    if (shape == 8) return launch_fused<3, 4, 1>(p, s);          // the eight-wave shape without NEXT (A/B of the shape alone)
     return launch_fused<3, 2, 1>(p, s);
 }
 
@@ -1172,6 +1295,7 @@ int wino_gemm_output_fused_incproj(const float* V, const float* U, const float* 
     p.generic_loop = generic_loop;
     p.V = V; p.U = U; p.bias = bias; p.out = out;
     p.w2 = W2; p.bias2 = bias2; p.res = x; p.C2 = C2;
+    p.w3 = nullptr; p.bias3 = nullptr; p.out3 = nullptr;
     p.TH = (H + 3) / 4; p.TW = (W + 3) / 4;
     const int64_t ntile = (int64_t)B * p.TH * p.TW;
     if (Cout != 64 || !wino_fused_inc_supported(ntile, Cin, Cout, C2)) return MM_ERR_UNSUPPORTED;

@@ -900,6 +900,52 @@ def test_resnet50_increase_conv_inside_the_fused_winograd_kernel(resnet, oracle,
     assert (resnet.get_vec(xt[1:2].contiguous()) - a[1:2]).abs().max().item() / scale < 1e-5
 
 
+def test_resnet50_next_blocks_reduce_conv_inside_the_fused_winograd_kernel(resnet, oracle, dev, monkeypatch):
+    """conv2_x block 2 (round 6): the fused kernel -- 3x3 + increase conv + residual + ReLU -- also runs block 3's 256 -> 64 reduce conv on
+    the 256-channel tile it has just computed (wino_fused.hip NEXT: a third MFMA chained from the accumulators, eight-wave workgroups with
+    both matrices in LDS) and writes both tensors; block 3 starts at its 3x3 layer.  MM_FUSE_NEXT=1 only: measured 0.3 ms per step SLOWER than
+    the separate launch (profiles/r06_ab_next_reduce.txt), so the default schedule keeps the launch; the path stays tested.  Against the
+    default form and the oracle: the K = 256 contraction is summed in another order (two 128-channel halves added at the end), not
+    bit-equal, far inside the tolerance.  Batch 3 leaves a ragged last workgroup (588 tiles / 64), batch 1 a lone one."""
+    from mimamo_net_amd.resnet50_extractor import Resnet50_Extractor
+    monkeypatch.setenv("MM_FUSE_NEXT", "1")
+    fused = Resnet50_Extractor(state_dict=weights.make_resnet50_state_dict(seed=0), device=dev)
+    monkeypatch.delenv("MM_FUSE_NEXT")
+    split = resnet
+    x = _images(3, 23)
+    want = oracle.resnet50_pool5(weights.make_resnet50_state_dict(seed=0), x)
+    xt = torch.from_numpy(x).to(dev)
+    scale = np.abs(want).max()
+    n_f = _count_conv_launches(lambda: fused.get_vec(xt))
+    n_s = _count_conv_launches(lambda: split.get_vec(xt))
+    assert n_s - n_f == 1, ("one 256 -> 64 launch fewer", n_f, n_s)
+    resnet = fused
+    try:
+        for mode in (1, 5):
+            resnet.set_winograd(mode)
+            split.set_winograd(mode)
+            a, b = resnet.get_vec(xt).cpu().numpy(), split.get_vec(xt).cpu().numpy()
+            assert not np.array_equal(a, b)                      # the knob really switches the schedule
+            d = np.abs(a - b).max() / scale
+            print("winograd %d: next-reduce-fused vs separate launches max rel %.2e; vs oracle %.2e / %.2e" % (
+                mode, d, np.abs(a - want).max() / scale, np.abs(b - want).max() / scale))
+            assert d < 1e-5, d
+            for g in (a, b):
+                mx, mean = np.abs(g - want).max() / scale, np.abs(g - want).mean() / scale
+                assert mx < POOL5_RTOL * 10 and mean < POOL5_RTOL
+                assert mx < POOL5_TIGHT_MAX and mean < POOL5_TIGHT_MEAN, ("regression bound", mx, mean)
+        resnet.set_winograd(4)        # the three-kernel form never takes the fused path
+        split.set_winograd(4)
+        assert torch.equal(resnet.get_vec(xt), split.get_vec(xt))
+    finally:
+        resnet.set_winograd(True)
+        split.set_winograd(True)
+    # deterministic, batch-invariant (a frame alone: 196 tiles = 3.06 workgroups)
+    a = resnet.get_vec(xt)
+    assert torch.equal(a, resnet.get_vec(xt))
+    assert (resnet.get_vec(xt[1:2].contiguous()) - a[1:2]).abs().max().item() / scale < 1e-5
+
+
 def test_resnet50_maxpool_and_reduce_conv_in_one_kernel(resnet, oracle, dev, monkeypatch):
     """pool1_3x3_s2 + conv2_1's 1x1 reduce conv (64 -> 64) as one kernel (pool_reduce.hip: the pooled values go from the max straight
     into the MFMA as its B operand) against the two-launch form (MM_FUSE_POOL=0) and the oracle; odd batch: 3 x 3136 pixels = 588

@@ -3,8 +3,7 @@
 #   gpurun -- 'bash tools/r05_cost_sheet.sh > gpurun_out/r05_conv2x_cost_sheet_measured.txt 2>&1'
 # Needs tools/_ab/libmeasure.so (MM_EXTRA_HIPCC_FLAGS=-DMM_MEASURE build: MM_WF_ABLATE / MM_WF_LDS_PAD, results wrong by construction).
 cd $GRAFT_REPO_ROOT
-cp mimamo-net_amd/libmimamo_hip.so /tmp/_orig.so
-cp tools/_ab/libmeasure.so mimamo-net_amd/libmimamo_hip.so
+export MM_LIB_PATH=$PWD/tools/_ab/libmeasure.so   # (never copied over the shipped library)
 PAT="inc256|incproj256|K=256 N=64 k1|wino_in6|maxpool"
 for rep in 1 2; do
 for cfg in "" "MM_WF_ABLATE=1" "MM_WF_ABLATE=3" "MM_WF_LDS_PAD=28000" "MM_WF_LDS_PAD=28000 MM_WF_ABLATE=3"; do
@@ -16,4 +15,3 @@ for rep in 1 2; do
 python tools/conv_bench.py 2048 56 56 256 64 1 1 0
 python tools/conv_bench.py 2048 56 75 256 64 1 1 0
 done
-cp /tmp/_orig.so mimamo-net_amd/libmimamo_hip.so
