@@ -46,38 +46,104 @@ FRAMES_PER_CLIP = 64
 EXAMPLE_VIDEO_FRAMES = 309      # api/readme.md:100 (utterance_1.mp4): 5 snippets of 64 (snippet_sampler.py:112-126)
 
 
+LIVE_CHILD_TIMEOUT_S = 40      # one profiler child (a healthy one takes ~5-8 s after the parent has paged the image in)
+LIVE_BUDGET_S = 80             # all profiler children together; a hung profiler costs ONE child timeout, then the leg gives up
+N_SIMDS = 256 * 4              # MI355X: 256 CUs x 4 SIMDs
+NOMINAL_CLOCK_GHZ = 2.4        # the clock PEAK_FP32_MFMA_TFLOPS is quoted at (MI355X_MICROARCH.md)
+
+
+def _profiler_child(cmd, env, timeout):
+    """One child under the profiler, in its OWN process group: on timeout the whole group is killed (the profiler forks the python child;
+    killing only the wrapper would leave a grandchild sharing the GPU with the legs that follow).  Returns (returncode | None, output)."""
+    import signal
+    import subprocess
+    p = subprocess.Popen(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, start_new_session=True,
+                         universal_newlines=True)
+    try:
+        out, _ = p.communicate(timeout=timeout)
+        return p.returncode, out
+    except subprocess.TimeoutExpired:
+        try:
+            os.killpg(p.pid, signal.SIGKILL)
+        except OSError:
+            pass
+        try:
+            out, _ = p.communicate(timeout=10)
+        except Exception:      # noqa: BLE001
+            out = ""
+        return None, out
+
+
+def schedule_flags(args):
+    """The flags of this run that change WHICH kernels a step launches: a profiler child must run the same schedule as its parent, or its
+    PMC bytes would be reported as 'measured live by this run' for another configuration (round-5 ADVICE)."""
+    f = ["--lanes", str(args.lanes), "--winograd", str(args.winograd)]
+    if args.no_winograd:
+        f.append("--no-winograd")
+    if args.from_f32:
+        f.append("--from-f32")
+    if args.stream_input:
+        f.append("--stream-input")
+    return f
+
+
 def measure_live_traffic(args, per_step):
-    """HBM traffic per step from rocprofv3 PMC counters, measured now: this script run twice as a child (1 timed + 1 warm-up step, no
-    extras) under `rocprofv3 --pmc FETCH_SIZE --kernel-trace` and `--pmc WRITE_SIZE --kernel-trace` -- the collection
-    MI355X_MICROARCH.md prescribes (separate passes; FETCH_SIZE doubled on gfx950), the same recipe as tools/pmc_traffic.sh.
-    Returns {"conv": bytes, "phase": bytes, "winograd_transforms": bytes, "seconds": s} or {"error": "..."}; never raises."""
+    """PMC counters of one step, measured now: this script run as a child (1 timed + 1 warm-up step, no extras) under
+    `rocprofv3 --pmc FETCH_SIZE --kernel-trace`, `--pmc WRITE_SIZE --kernel-trace` -- the collection MI355X_MICROARCH.md prescribes for HBM
+    bytes (separate passes; FETCH_SIZE doubled on gfx950), the recipe of tools/pmc_traffic.sh -- and a third pass with SQ / GRBM counters
+    (`SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE`) for the sustained clock of the conv launches and the VALU-issue
+    floor of the phase kernels.  Returns {"conv": bytes, "phase": bytes, "winograd_transforms": bytes, "seconds": s, "clock": {...} | None,
+    "valu": {...} | None} or {"error": "..."}; never raises, never takes longer than LIVE_BUDGET_S (+ one kill grace)."""
     import csv
     import glob
     import shutil
-    import subprocess
     import tempfile
     t0 = time.time()
     exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
     if not exe:
         return {"error": "rocprofv3 not found"}
     steps, warm = 1, 1
-    nsteps = steps + warm + 2          # + the two single-stream steps of the child's roofline leg
     groups = {"conv": ("conv_mfma_kernel", "wino_fused_kernel"), "winograd_transforms": ("wino_in", "wino_out"),
               "phase": ("pyramid_frame_kernel", "pyramid_kernel", "phase_window2_kernel")}
+    phase_kernels = {"pyramid_frame": "pyramid_frame_kernel", "phase_window2<48>": "phase_window2_kernel<48", "phase_window2<24>": "phase_window2_kernel<24"}
     tot = {g: {} for g in groups}
-    tmp = tempfile.mkdtemp(prefix="mm_pmc_", dir="/tmp")
+    tmp = None
     try:
+        tmp = tempfile.mkdtemp(prefix="mm_pmc_", dir="/tmp")
         env = dict(os.environ, TMPDIR="/tmp")
-        for c in ("FETCH_SIZE", "WRITE_SIZE"):
-            d = os.path.join(tmp, c)
-            cmd = [exe, "--pmc", c, "--kernel-trace", "--output-format", "csv", "-d", d, "-o", "out", "--", sys.executable,
-                   os.path.abspath(__file__), "--steps", str(steps), "--warmup", str(warm), "--clips", str(per_step), "--lanes", str(args.lanes),
-                   "--no-cpu-baseline", "--no-extra", "--no-live-traffic"]
-            r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=90)
+
+        def child(tag, counters):
+            """-> (counter_collection.csv, kernel_trace.csv, steps the child ran) or raises RuntimeError"""
+            left = LIVE_BUDGET_S - (time.time() - t0)
+            if left < 10:
+                raise RuntimeError("live PMC budget of %d s used up before the %s pass" % (LIVE_BUDGET_S, tag))
+            d = os.path.join(tmp, tag)
+            cmd = [exe, "--pmc"] + counters + ["--kernel-trace", "--output-format", "csv", "-d", d, "-o", "out", "--", sys.executable,
+                                               os.path.abspath(__file__), "--steps", str(steps), "--warmup", str(warm), "--clips", str(per_step),
+                                               "--no-cpu-baseline", "--no-extra", "--no-live-traffic"] + schedule_flags(args)
+            rc, out = _profiler_child(cmd, env, min(LIVE_CHILD_TIMEOUT_S, left))
+            if rc is None:
+                raise RuntimeError("rocprofv3 --pmc %s: no result after %d s (process group killed)" % (tag, min(LIVE_CHILD_TIMEOUT_S, left)))
             files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
-            if r.returncode != 0 or not files:
-                return {"error": "rocprofv3 --pmc %s: rc %d, %d counter files" % (c, r.returncode, len(files))}
-            with open(files[0]) as f:
+            traces = glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True)
+            if rc != 0 or not files:
+                raise RuntimeError("rocprofv3 --pmc %s: rc %d, %d counter files" % (tag, rc, len(files)))
+            # the child says how many steps of the hot path it ran (its line's `hot_path_steps_executed`): the divisor of the per-step bytes
+            n = None
+            for line in out.splitlines():
+                if line.startswith('{"metric"'):
+                    try:
+                        n = json.loads(line).get("hot_path_steps_executed")
+                    except ValueError:
+                        pass
+            if not n:
+                raise RuntimeError("the %s child printed no bench line with hot_path_steps_executed" % tag)
+            return files[0], (traces[0] if traces else None), int(n)
+
+        nsteps = {}
+        for c in ("FETCH_SIZE", "WRITE_SIZE"):
+            path, _, nsteps[c] = child(c, [c])
+            with open(path) as f:
                 for row in csv.DictReader(f):
                     if row.get("Counter_Name") != c:
                         continue
@@ -88,13 +154,91 @@ def measure_live_traffic(args, per_step):
         for g in groups:
             if "FETCH_SIZE" not in tot[g] or "WRITE_SIZE" not in tot[g]:
                 return {"error": "no %s kernels in the counter files" % g}
-            out[g] = (tot[g]["FETCH_SIZE"] * 1024 * 2 + tot[g]["WRITE_SIZE"] * 1024) / nsteps
+            out[g] = tot[g]["FETCH_SIZE"] * 1024 * 2 / nsteps["FETCH_SIZE"] + tot[g]["WRITE_SIZE"] * 1024 / nsteps["WRITE_SIZE"]
+        out["steps_profiled"] = nsteps["FETCH_SIZE"]
+        # third pass (optional: a failure here keeps the traffic): sustained clock + matrix-pipe busy of the conv launches, VALU instructions
+        # of the phase kernels
+        out["clock"], out["valu"] = None, None
+        try:
+            path, trace, n3 = child("SQ", ["SQ_INSTS_VALU", "SQ_INSTS_MFMA", "SQ_VALU_MFMA_BUSY_CYCLES", "GRBM_GUI_ACTIVE"])
+            out["clock"], out["valu"] = sq_pass_summary(path, trace, n3, groups["conv"], phase_kernels)
+        except Exception as e:      # noqa: BLE001
+            out["sq_pass_error"] = "%s: %s" % (type(e).__name__, e)
         out["seconds"] = time.time() - t0
         return out
     except Exception as e:      # noqa: BLE001 -- a profiler problem must never take the bench line down
-        return {"error": "%s: %s" % (type(e).__name__, e)}
+        return {"error": "%s: %s" % (type(e).__name__, e), "seconds": time.time() - t0}
     finally:
-        shutil.rmtree(tmp, ignore_errors=True)
+        if tmp:
+            shutil.rmtree(tmp, ignore_errors=True)
+
+
+def sq_pass_summary(counter_csv, trace_csv, nsteps, conv_pats, phase_kernels):
+    """From one `rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace` run:
+    clock = {"GHz": sum(GRBM_GUI_ACTIVE / 8 XCDs) / sum(kernel durations) over the conv launches (MI355X_MICROARCH.md: effective clock =
+             GRBM_GUI_ACTIVE / kernel wall time), "mfma_busy": SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x cycles)};
+    valu = {tag: non-MFMA VALU wave instructions per step} for the phase kernels.  Pure function of the two csv files (CPU-tested)."""
+    import csv
+    gui = busy = dur_ns = 0.0
+    valu = {t: 0.0 for t in phase_kernels}
+    with open(counter_csv) as f:
+        for row in csv.DictReader(f):
+            name, c, v = row["Kernel_Name"], row.get("Counter_Name"), float(row["Counter_Value"])
+            if any(p_ in name for p_ in conv_pats):
+                if c == "GRBM_GUI_ACTIVE":
+                    gui += v
+                elif c == "SQ_VALU_MFMA_BUSY_CYCLES":
+                    busy += v
+            for t, pat in phase_kernels.items():
+                if pat in name:
+                    if c == "SQ_INSTS_VALU":
+                        valu[t] += v
+                    elif c == "SQ_INSTS_MFMA":
+                        valu[t] -= v
+    clock = None
+    if trace_csv and gui > 0:
+        with open(trace_csv) as f:
+            for row in csv.DictReader(f):
+                if any(p_ in row["Kernel_Name"] for p_ in conv_pats):
+                    dur_ns += int(row["End_Timestamp"]) - int(row["Start_Timestamp"])
+        if dur_ns > 0:
+            clock = {"GHz": gui / 8.0 / dur_ns, "mfma_busy": busy / (N_SIMDS * gui / 8.0),
+                     "how": "sum over the conv launches of GRBM_GUI_ACTIVE / 8 XCDs, divided by the sum of their kernel-trace durations "
+                            "(under the profiler: launches serialised); mfma_busy = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x those cycles)"}
+    return clock, ({t: v / nsteps for t, v in valu.items()} if any(v > 0 for v in valu.values()) else None)
+
+
+def phase_floors(live_rows, n_frames, valu_insts=None):
+    """Per-kernel floors of the phase stage (round-5 verdict: the stage's floor is NOT the pyramid's MFMA floor alone -- the window kernels
+    execute no MFMA and are VALU / LDS-issue bound).  live_rows: (cat, work, ms, tag) of one single-stream step from the library's
+    measurement hook; valu_insts: {tag: non-MFMA VALU wave instructions per step} from the live SQ pass, or None.
+      floor_hbm_ms  = the kernel's algorithmic bytes / 8 TB/s (pyramid: frame in + the four planes per (frame, band, level) it hands to
+                      the window kernels are INTERNAL traffic, not counted; windows: the difference planes written)
+      floor_mfma_ms = pyramid only: 4 344 v_mfma_f32_16x16x4_f32 = 8.9 MFLOP per frame / 157.3 TFLOP/s
+      floor_valu_ms = VALU wave instructions x 4 issue cycles / 1 024 SIMDs / 2.4 GHz (a wave64 VALU instruction occupies its SIMD 4 cycles)
+    A kernel's floor is the largest of its floors; the stage's limiting floor is the SUM of the kernels' floors (they run back to back)."""
+    kern = {}
+    for c_, w_, t_, tag in live_rows:
+        if c_ not in (1, 2):
+            continue
+        k = kern.setdefault(tag, {"ms": 0.0, "bytes": 0.0, "launches": 0})
+        k["ms"] += t_
+        k["bytes"] += w_
+        k["launches"] += 1
+    total = 0.0
+    for tag, k in kern.items():
+        fl = {"hbm": k["bytes"] / (PEAK_HBM_GBS * 1e9) * 1e3}
+        if tag.startswith("pyramid"):
+            fl["mfma"] = n_frames * 4344 * 2048.0 / (PEAK_FP32_MFMA_TFLOPS * 1e12) * 1e3
+        if valu_insts and valu_insts.get(tag):
+            fl["valu"] = valu_insts[tag] * 4.0 / N_SIMDS / (NOMINAL_CLOCK_GHZ * 1e9) * 1e3
+        for n_, v in fl.items():
+            k["floor_%s_ms" % n_] = v
+        k["limiter"] = max(fl, key=fl.get)
+        k["floor_ms"] = fl[k["limiter"]]
+        k["frac_of_floor"] = k["floor_ms"] / k["ms"] if k["ms"] > 0 else None
+        total += k["floor_ms"]
+    return kern, total
 
 
 def kernel_source_hash():
@@ -255,6 +399,7 @@ class HipCompute(object):
         self.pool = {}          # clip content id -> row in the device-resident pool
         self.frames_u8 = None   # [P*64,112,112,3] uint8
         self.pre = None         # (gray, rgb) of the pool for --from-f32
+        self.n_forward = 0      # passes of the hot path this process has run (a profiler child reports it: the divisor of per-step counters)
 
     def load(self, content_ids, share=None):
         """Synthetic clips (seed 1000 + id) -> HBM, outside the timed region.
@@ -351,6 +496,7 @@ class HipCompute(object):
         return self._forward(ins, len(content_ids), lanes, not self.args.from_f32)
 
     def _forward(self, ins, n_clips, lanes, u8):
+        self.n_forward += 1
         lengths = [FRAMES_PER_CLIP] * n_clips
         if lanes > 1:
             return self.hot.forward_lanes(ins, lengths, lanes, independent_clips=True, from_u8=u8)
@@ -655,6 +801,7 @@ def run_rank(args):
     import shutil
     shutil.rmtree(os.path.dirname(dump_path), ignore_errors=True)
     conv_tflops = work_[0] / (ms[0] * 1e-3) / 1e12
+    result["hot_path_steps_executed"] = comp.n_forward     # warm-up + timed + the two single-stream steps of this leg (read by a profiler parent)
     phase_ms = ms[1] + ms[2]
     phase_gbs = (work_[1] + work_[2]) / (phase_ms * 1e-3) / 1e9
 
@@ -752,15 +899,36 @@ def run_rank(args):
                                 "GB_per_s": (work_[3] / (ms[3] * 1e-3) / 1e9) if ms[3] > 0 else None,
                                 "pmc_bytes_per_step_live": live_traffic.get("winograd_transforms") if live_traffic else None},
         "traffic_source": "live" if live_note else ("committed" if traffic else None)}
+    # (round 6) the 157.3 TFLOP/s denominator is the peak at the NOMINAL 2.4 GHz; under fp32-MFMA load the chip sustains 2.0-2.4 GHz.  `frac`
+    # stays on the nominal peak; beside it the clock the conv launches actually ran at (GRBM_GUI_ACTIVE / kernel time, the live SQ pass) and
+    # the fraction of the peak AT THAT CLOCK, so that "0.89 at 2.36 GHz, 91 % busy" reads as done and "0.60 at 2.17 GHz, 61 % busy" as open
+    clk = live_traffic.get("clock") if live_traffic else None
+    result["roofline"]["sustained_clock_GHz"] = clk["GHz"] if clk else None
+    result["roofline"]["mfma_busy_frac"] = clk["mfma_busy"] if clk else None
+    result["roofline"]["peak_at_sustained_clock"] = PEAK_FP32_MFMA_TFLOPS * clk["GHz"] / NOMINAL_CLOCK_GHZ if clk else None
+    result["roofline"]["frac_at_sustained_clock"] = conv_tflops / (PEAK_FP32_MFMA_TFLOPS * clk["GHz"] / NOMINAL_CLOCK_GHZ) if clk else None
+    result["roofline"]["clock_note"] = (clk["how"] if clk else
+                                        "no live SQ / GRBM pass (%s)" % ((live_traffic or {}).get("sq_pass_error") or (live_traffic or {}).get("error")
+                                                                         or "not requested: --no-extra / --no-live-traffic / N > 1"))
     # both floors of the phase stage: HBM (algorithmic bytes at 8 TB/s) and the matrix pipes (pyramid_frame_kernel: 4 344
     # v_mfma_f32_16x16x4_f32 = 8.9 MFLOP per frame) -- the MFMA floor is the higher one
     ph_floor_hbm = (work_[1] + work_[2]) / (PEAK_HBM_GBS * 1e9) * 1e3
     ph_floor_mfma = n_frames * 4344 * 2048.0 / (PEAK_FP32_MFMA_TFLOPS * 1e12) * 1e3
+    ph_valu = live_traffic.get("valu") if live_traffic else None
+    ph_kernels, ph_floor_sum = phase_floors(live, n_frames, ph_valu)
+    ph_floor_valu = sum(k.get("floor_valu_ms", 0.0) for k in ph_kernels.values()) if ph_valu else None
     result["roofline_phase"] = {"bound": "hbm", "kernel": "pyramid_frame_kernel + phase_window2_kernel<48|24> (all phase-stage launches of one step)",
                                 "achieved": phase_gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": phase_gbs / PEAK_HBM_GBS,
                                 "floor_hbm_ms": ph_floor_hbm, "floor_mfma_ms": ph_floor_mfma,
-                                "limiting_floor": "mfma" if ph_floor_mfma > ph_floor_hbm else "hbm",
-                                "frac_of_limiting_floor": max(ph_floor_hbm, ph_floor_mfma) / phase_ms,
+                                "floor_valu_ms": ph_floor_valu,
+                                # per kernel the largest of its floors (HBM on its algorithmic bytes, MFMA for the pyramid, VALU issue from the
+                                # live SQ_INSTS_VALU count), summed over the kernels: they run back to back on one stream
+                                "kernels": ph_kernels,
+                                "limiting_floor_ms": ph_floor_sum,
+                                "limiting_floor": "+".join("%s:%s" % (t, k["limiter"]) for t, k in sorted(ph_kernels.items())),
+                                "frac_of_limiting_floor": ph_floor_sum / phase_ms if phase_ms > 0 else None,
+                                "valu_source": "live (rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_MFMA, this run)" if ph_valu else
+                                               "none: no live SQ pass -- floors are HBM / MFMA only",
                                 "traffic": ptraffic, "traffic_file": ptraffic_file, "bytes_per_step": work_[1] + work_[2], "ms_per_step": phase_ms,
                                 "ms_pyramid": ms[1], "ms_window": ms[2]}
 

@@ -18,6 +18,11 @@ struct ConvParams {
     int kh, kw, stride, pad;
     int K, Kpad;
     int korder;      // 0: k=(r,s,c)   1: k=(c/16,r,s,c%16), needs Cin % 16 == 0   2: packed 3-channel rows (see conv_mfma.hip)
+                     //    FINITE INPUTS ASSUMED for korder 2 on the unrolled stem loop (KMODE 9): k-quads past K = 168 and rows past M read real
+                     //    memory (the window's 8th row, row m_base's pixels) and rely on zero weights / never-stored rows, so an Inf / NaN in
+                     //    that extra row gives 0 * Inf = NaN in output pixels whose 7x7 window does not contain it -- base mode 5 (no_sched)
+                     //    and the reference's conv do not.  pool5 averages every pixel anyway, so a non-finite frame poisons its features in
+                     //    both forms; preprocessing (uint8 in) cannot produce one.
     int relu;
     int force_tile;  // 0 auto, 1 = 128x128, 2 = 128x64, 3 = 64x64, 4 = 256x64, 5 = 128x256 (8 waves, 1x1 only), 16+bits = ablation build
     int ablate;

@@ -575,7 +575,7 @@ int mm_resnet50_forward(mm_resnet50_t* h, const float* images, int nchw, int64_t
         }
         rc = run_layer(h->stem3, x0, B, 230, 230, 3, 0, big[0], 64, 0, nullptr, 0, s, &Ho, &Wo, 0, h->no_sched, hpool);
     } else {
-        rc = run_layer(h->stem, x0, B, H, W, 4, 0, big[0], 64, 0, nullptr, 0, s, &Ho, &Wo);   // NHWC4: K = 196
+        rc = run_layer(h->stem, x0, B, H, W, 4, 0, big[0], 64, 0, nullptr, 0, s, &Ho, &Wo, 0, h->no_sched);   // NHWC4: K = 196
     }
     if (rc != MM_OK) return rc;
     if (Ho != 112 || Wo != 112) return MM_ERR_UNSUPPORTED;
@@ -650,7 +650,7 @@ int mm_resnet50_forward(mm_resnet50_t* h, const float* images, int nchw, int64_t
             if (rc == MM_ERR_UNSUPPORTED) rc = run_layer_wino(Bk.conv3, y1, B, H1, W1, y2, wv, wm, wm_, s, nullptr, nullptr, nullptr, false, x3, h->wf_generic, ns);
             H2 = H1; W2 = W1;
         } else {
-            rc = run_layer(Bk.conv3, y1, B, H1, W1, Bk.reduce.cout, 0, y2, Bk.conv3.cout, 0, nullptr, 0, s, &H2, &W2);
+            rc = run_layer(Bk.conv3, y1, B, H1, W1, Bk.reduce.cout, 0, y2, Bk.conv3.cout, 0, nullptr, 0, s, &H2, &W2, 0, ns);   // ns: the twin runs base mode 1, not the unrolled mode 11
         }
         if (rc != MM_OK) return rc;
         if (inc_done) {

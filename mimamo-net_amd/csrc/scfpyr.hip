@@ -207,7 +207,13 @@ int mm_scfpyr_create(mm_scfpyr_t** out, int size, int height, int nbands, int sc
             if (4 * k == 3 * n) { tw[2 * k] = 0.0; tw[2 * k + 1] = -1.0; }
         }
         hipError_t er = hipMalloc((void**)dst, tw.size() * sizeof(double));
-        if (er == hipSuccess) er = hipMemcpy(*dst, tw.data(), tw.size() * sizeof(double), hipMemcpyHostToDevice);
+        if (er == hipSuccess) {
+            er = hipMemcpy(*dst, tw.data(), tw.size() * sizeof(double), hipMemcpyHostToDevice);
+            if (er != hipSuccess) {            // the caller only records a table it got hipSuccess for: free it here or it leaks
+                (void)hipFree(*dst);
+                *dst = nullptr;
+            }
+        }
         return er;
     };
     if (e == hipSuccess) e = upload_twiddle(size, &h->d_twiddle);

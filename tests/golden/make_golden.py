@@ -438,12 +438,45 @@ def g11_nondefault(ref):
     print("G11", out["a_out"].reshape(-1, 2)[:2], q0.shape, q1.shape, out["b_out"].reshape(-1, 2)[:2])
 
 
+def g13_resnet50_extractor_plumbing(ref):
+    """The reference's OWN code on the ResNet50 row, executed for the first time: `Resnet50_Extractor(benchmark_dir, model_name,
+    'pool5_7x7_s1')` (api/resnet50_extractor.py:14-41: `load_model`'s importlib exec of `<benchmark_dir>/ferplus/<model_name>.py` and its
+    `weights_path=` factory call, api/utils/model_utils.py:44-79; `.eval()`; `meta` -> `compose_transforms`) and `.get_vec`
+    (:74-83: forward hook on `_modules['pool5_7x7_s1']`, copy into a [bs,2048,1,1] CPU tensor, `relu(squeeze())`) on a STAND-IN
+    definition file + deterministic weights (tests/golden/standin_model.py -- this build's restatement of the graph, the third-party
+    file is not available offline).  Pins the plumbing (layer name, hook, squeeze, meta, key layout of the .pth), not the arithmetic."""
+    import tempfile
+    import standin_model
+    import resnet50_extractor as rex
+    tmp = tempfile.mkdtemp(prefix="mm_g13_")
+    bdir, _ = standin_model.write_benchmark_dir(os.path.join(tmp, "pytorch-benchmarks"), weights, seed=5)
+    ext = rex.Resnet50_Extractor(benchmark_dir=bdir, model_name="resnet50_ferplus_dag", feature_layer="pool5_7x7_s1")
+    assert not ext.model.training
+    x = resnet_images(2, 13)
+    with torch.no_grad():
+        v2 = ext.get_vec(torch.from_numpy(x))
+        v1 = ext.get_vec(torch.from_numpy(x[:1]))                       # quirk Q8: squeeze() collapses bs = 1 to [2048]
+    out = {"weight_seed": 5, "image_seed": 13, "vec_bs2": v2.numpy(), "vec_bs1": v1.numpy(),
+           "meta_mean": np.asarray(ext.model.meta["mean"], dtype=np.float64), "meta_std": np.asarray(ext.model.meta["std"]),
+           "meta_imageSize": np.asarray(ext.model.meta["imageSize"]),
+           "frame_index": np.asarray([ext.get_frame_index("/a/b_aligned/frame_det_00_000123.bmp")]),
+           "hooked_layer_type": np.asarray(type(ext.model._modules.get(ext.feature_layer)).__name__),
+           "n_modules": np.asarray(len(ext.model._modules))}
+    import shutil
+    shutil.rmtree(tmp, ignore_errors=True)
+    print("G13", out["vec_bs2"].shape, out["vec_bs1"].shape, float(np.abs(out["vec_bs2"]).max()), out["hooked_layer_type"], out["n_modules"])
+    np.savez_compressed(os.path.join(HERE, "resnet50_plumbing.npz"), **out)
+
+
 if __name__ == "__main__":
     if sys.argv[1:] in ([], ["g5"]):
         g5_resnet50_hf()   # before ref_shim.load(): its torchvision stub confuses transformers' optional-dependency probe
         if sys.argv[1:]:
             sys.exit(0)
     ref = ref_shim.load()
+    if sys.argv[1:] == ["g13"]:
+        g13_resnet50_extractor_plumbing(ref)
+        sys.exit(0)
     if sys.argv[1:] == ["g12"]:
         g12_sampler_keywords(ref)
         sys.exit(0)
@@ -470,4 +503,5 @@ if __name__ == "__main__":
     g10_train_phase(ref)
     g11_nondefault(ref)
     g12_sampler_keywords(ref)
+    g13_resnet50_extractor_plumbing(ref)
     os.system("ls -la %s" % HERE)

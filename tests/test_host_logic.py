@@ -359,6 +359,84 @@ def test_live_traffic_leg_never_raises_without_a_profiler(monkeypatch):
     assert out == {"error": "rocprofv3 not found"}
 
 
+def _bench():
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import bench
+    return bench
+
+
+def test_live_traffic_leg_survives_a_hung_profiler(monkeypatch, tmp_path):
+    """Round-5 verdict item 5: with a `rocprofv3` that never returns, the default bench run must still print its line in time.  The live
+    leg runs every profiler child in its own process group under a per-child timeout, kills the GROUP (the profiler forks the python
+    child) and gives up after the first timeout instead of trying the remaining passes."""
+    import shutil
+    import subprocess
+    import time
+    import types
+    bench = _bench()
+    fake = tmp_path / "rocprofv3"
+    pidfile = tmp_path / "grandchild.pid"
+    # a profiler that forks a grandchild and hangs: both must be gone after the timeout
+    fake.write_text("#!/bin/bash\nsleep 600 &\necho $! > %s\nsleep 600\n" % pidfile)
+    fake.chmod(0o755)
+    monkeypatch.setattr(shutil, "which", lambda name: str(fake))
+    monkeypatch.setattr(bench, "LIVE_CHILD_TIMEOUT_S", 2)
+    monkeypatch.setattr(bench, "LIVE_BUDGET_S", 30)
+    args = types.SimpleNamespace(lanes=3, winograd=1, no_winograd=False, from_f32=False, stream_input=False)
+    t0 = time.time()
+    out = bench.measure_live_traffic(args, 32)
+    assert time.time() - t0 < 15, "one child timeout, not one per pass"
+    assert "error" in out and "no result after 2 s" in out["error"], out
+    gpid = int(pidfile.read_text())
+    time.sleep(0.2)
+    alive = subprocess.run(["ps", "-o", "stat=", "-p", str(gpid)], stdout=subprocess.PIPE, universal_newlines=True).stdout.strip()
+    assert alive == "" or alive.startswith("Z"), "the profiler's grandchild survived the timeout: %r" % alive
+
+
+def test_live_traffic_child_runs_the_parents_schedule():
+    """the profiler child must launch the kernels its parent launches (flags that change the schedule are forwarded)."""
+    import types
+    bench = _bench()
+    a = types.SimpleNamespace(lanes=2, winograd=4, no_winograd=True, from_f32=True, stream_input=False)
+    f = bench.schedule_flags(a)
+    assert f == ["--lanes", "2", "--winograd", "4", "--no-winograd", "--from-f32"]
+    bench.parse_args(["--steps", "1"] + f)           # every forwarded flag is one bench.py accepts
+
+
+def test_sq_pass_summary_and_phase_floors(tmp_path):
+    """Round-5 verdict item 4: the line carries the sustained clock of the conv launches (GRBM_GUI_ACTIVE / kernel time), the fraction
+    of the MFMA peak at that clock, and per-kernel floors of the phase stage incl. the VALU-issue floor (SQ_INSTS_VALU x 4 cycles /
+    1 024 SIMDs / 2.4 GHz) -- the verdict's own example: 8.88e7 instructions -> 0.144 ms for phase_window2_kernel<48>."""
+    bench = _bench()
+    cc = tmp_path / "cc.csv"
+    tr = tmp_path / "kt.csv"
+    rows = [("void mm::conv_mfma_kernel<128,256>(p)", "GRBM_GUI_ACTIVE", 8 * 2.0e6), ("void mm::conv_mfma_kernel<128,256>(p)", "SQ_VALU_MFMA_BUSY_CYCLES", 0.9 * 1024 * 2.0e6),
+            ("void mm::wino_fused_kernel<3,2>(p)", "GRBM_GUI_ACTIVE", 8 * 1.0e6), ("void mm::wino_fused_kernel<3,2>(p)", "SQ_VALU_MFMA_BUSY_CYCLES", 0.6 * 1024 * 1.0e6),
+            ("void mm::phase_window2_kernel<48>(a)", "SQ_INSTS_VALU", 2 * 8.88e7), ("void mm::phase_window2_kernel<48>(a)", "SQ_INSTS_MFMA", 0.0),
+            ("void mm::phase_window2_kernel<24>(a)", "SQ_INSTS_VALU", 2 * 2.4e7),
+            ("void mm::pyramid_frame_kernel(a)", "SQ_INSTS_VALU", 2 * 5.0e7), ("void mm::pyramid_frame_kernel(a)", "SQ_INSTS_MFMA", 2 * 8.9e6),
+            ("void mm::wino_in6_kernel(a)", "GRBM_GUI_ACTIVE", 1e9)]
+    cc.write_text("Kernel_Name,Counter_Name,Counter_Value\n" + "".join('"%s",%s,%r\n' % r for r in rows))
+    tr.write_text("Kernel_Name,Start_Timestamp,End_Timestamp\n"
+                  '"void mm::conv_mfma_kernel<128,256>(p)",1000,1001000\n"void mm::wino_fused_kernel<3,2>(p)",2000000,2500000\n"void mm::wino_in6_kernel(a)",0,5\n')
+    pk = {"pyramid_frame": "pyramid_frame_kernel", "phase_window2<48>": "phase_window2_kernel<48", "phase_window2<24>": "phase_window2_kernel<24"}
+    clock, valu = bench.sq_pass_summary(str(cc), str(tr), 2, ("conv_mfma_kernel", "wino_fused_kernel"), pk)
+    assert abs(clock["GHz"] - 3.0e6 / 1.5e6) < 1e-9                      # 3.0e6 cycles in 1.5 ms = 2.0 GHz
+    assert abs(clock["mfma_busy"] - (0.9 * 2 + 0.6 * 1) / 3) < 1e-9
+    assert valu == {"pyramid_frame": 5.0e7 - 8.9e6, "phase_window2<48>": 8.88e7, "phase_window2<24>": 2.4e7}
+    live = [(0, 1e12, 9.0, "M=1 K=2 N=3"), (1, 2048 * 9216.0, 0.317, "pyramid_frame"), (2, 2048 * 221184.0, 0.40, "phase_window2<48>"),
+            (2, 2048 * 55296.0, 0.11, "phase_window2<24>")]
+    kern, total = bench.phase_floors(live, 2048, valu)
+    assert abs(kern["phase_window2<48>"]["floor_valu_ms"] - 0.1445) < 1e-3 and kern["phase_window2<48>"]["limiter"] == "valu"
+    assert kern["pyramid_frame"]["limiter"] == "mfma" and abs(kern["pyramid_frame"]["floor_mfma_ms"] - 0.1158) < 1e-3
+    assert abs(total - sum(k["floor_ms"] for k in kern.values())) < 1e-12 and total > 0.116 + 0.144
+    # without the SQ pass the floors fall back to HBM / MFMA and say so
+    kern2, total2 = bench.phase_floors(live, 2048, None)
+    assert "floor_valu_ms" not in kern2["phase_window2<48>"] and kern2["phase_window2<48>"]["limiter"] == "hbm" and total2 < total
+
+
 def test_every_profile_file_the_docs_quote_exists():
     """DESIGN.md / README.md / INTEGRATION.md and the profiles / tools indexes back their numbers with files under profiles/ (same-box A/B
     logs, rocprof summaries): a renamed or dropped log must not leave a dangling citation behind."""

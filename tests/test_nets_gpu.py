@@ -541,6 +541,37 @@ def test_checkpoints_in_the_third_party_layout_load_from_disk(oracle, dev, tmp_p
     assert res["v"].shape == (20, 2) and np.isfinite(res["v"].values).all()
 
 
+def test_g13_drop_in_extractor_on_the_directory_the_real_reference_class_ran_on(golden, dev, tmp_path):
+    """G13 (tests/golden/make_golden.py): the REAL `Resnet50_Extractor(benchmark_dir, model_name, 'pool5_7x7_s1').get_vec`
+    (api/resnet50_extractor.py:14-41,74-83; `load_model`, api/utils/model_utils.py:65-79) was run on a stand-in
+    `<benchmark_dir>/ferplus/resnet50_ferplus_dag.{py,pth}` (tests/golden/standin_model.py).  The drop-in class pointed at the same
+    directory -- same constructor call, definition file read with `ast`, `.pth` in the third-party key layout incl. the unused
+    classifier and `num_batches_tracked` -- returns the same [bs,2048] features (on the device, bs = 1 stays [1,2048]: quirk Q8)."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    import standin_model
+    from mimamo_net_amd.resnet50_extractor import Resnet50_Extractor
+    g = golden("resnet50_plumbing")
+    bdir, _ = standin_model.write_benchmark_dir(tmp_path / "pytorch-benchmarks", weights, seed=int(g["weight_seed"]))
+    ext = Resnet50_Extractor(benchmark_dir=bdir, model_name="resnet50_ferplus_dag", feature_layer="pool5_7x7_s1")
+    np.testing.assert_array_equal(np.asarray(ext.meta["mean"], dtype=np.float64), g["meta_mean"])
+    assert ext.get_frame_index("/a/b_aligned/frame_det_00_000123.bmp") == int(g["frame_index"][0])
+    x = weights.det_uniform("resnet.img", (2, 3, 224, 224), 0.0, 1.0, int(g["image_seed"]))
+    x = (x * np.float32(255.0) - np.asarray(weights.RESNET50_MEAN, dtype=np.float32)[None, :, None, None]).astype(np.float32)
+    got = ext.get_vec(torch.from_numpy(x).to(dev))
+    assert got.is_cuda and tuple(got.shape) == (2, 2048)
+    want = g["vec_bs2"]
+    scale = np.abs(want).max()
+    err = np.abs(got.cpu().numpy() - want)
+    print("g13: max rel %.2e mean rel %.2e" % (err.max() / scale, err.mean() / scale))
+    assert err.max() / scale < 1e-4 and err.mean() / scale < 1e-5            # contract (SURVEY 8d)
+    assert err.max() / scale < 2.5e-6 and err.mean() / scale < 2.5e-7        # regression bound
+    one = ext.get_vec(torch.from_numpy(x[:1]).to(dev))
+    assert tuple(one.shape) == (1, 2048)
+    assert np.abs(one.cpu().numpy()[0] - g["vec_bs1"]).max() / scale < 2.5e-6
+    ext.close()
+
+
 @pytest.mark.parametrize("variant", [(0, 0), (0, 1), (1, 0)])
 def test_resnet50_graph_variants_vs_oracle_and_third_party(oracle, golden, dev, variant):
     """The parts of the third-party graph the reference's code does not pin: stride 2 on a stage's first 1x1 (1) or on
@@ -663,13 +694,15 @@ def test_conv_engine_scheduled_1x1_loop_is_bit_identical_to_modes_3_and_6(resnet
     in the loop) and mode 5 -- with the pooling epilogue (MM_FUSE_POOL=2, default) on both."""
     from mimamo_net_amd.resnet50_extractor import Resnet50_Extractor
     sd = weights.make_resnet50_state_dict(seed=0)
-    for env, n in ((None, 3), (("MM_FUSE_PROJ", "0"), 2), (None, 64)):
+    # (round 6, ADVICE: the twin now also keeps base mode 1 on the direct-form 3x3 layers and mode 4 on the NHWC4 stem; the last case puts
+    #  the stage strides on the 3x3 layers, which then run the direct form -- unrolled mode 11 against base mode 1 -- whatever the Winograd mode)
+    for env, n, kw in ((None, 3, {}), (("MM_FUSE_PROJ", "0"), 2, {}), (None, 64, {}), (None, 2, {"stride_on_first_1x1": False})):
         if env:
             monkeypatch.setenv(*env)
         xt = torch.from_numpy(_images(n, 41)).to(dev)
-        new = Resnet50_Extractor(state_dict=sd, device=dev)
+        new = Resnet50_Extractor(state_dict=sd, device=dev, **kw)
         monkeypatch.setenv("MM_CONV_SCHED", "0")
-        twin = Resnet50_Extractor(state_dict=sd, device=dev)
+        twin = Resnet50_Extractor(state_dict=sd, device=dev, **kw)
         monkeypatch.delenv("MM_CONV_SCHED")
         for mode in ((True, 0) if n < 64 else (True,)):
             new.set_winograd(mode)
