@@ -40,6 +40,7 @@ struct ConvParams {
     int H2, W2, C2, in2_cstride, in2_coff, stride2;
     int sched1x1;    // set by conv_forward: 1x1 layer with K % 16 == 0 on the scheduled loop (conv_mfma.hip KMODE 7 / 8)
     int no_sched;    // 1: keep modes 3 / 6 for such a layer (the parity twin of the scheduled loop)
+    int use_panel;   // 1: a layer conv_panel.hip applies to runs there (MM_CONV_PANEL=1: opt-in, measured slower than the engine -- the tested twin)
     int x3;          // 1: 1x1 layer on the bf16 matrix pipes through a three-way bf16 split of both fp32 operands (conv_mfma.hip X3; `extra` only)
     // exact division of a row index m < 2^31 by Ho * Wo and by Wo as multiply-high + shift (filled by conv_forward; the emulated 32-bit divisions of
     // the tile prologue were a third of its vector instructions, and vector instructions are matrix time on this chip)
@@ -50,6 +51,11 @@ struct ConvParams {
 };
 
 int conv_forward(const ConvParams& p, hipStream_t stream);
+// (round 6) 1x1 layers with K = 256 (or 128) and N a multiple of 256, N >= 512, stride 1: the 128-row activation panel resident in LDS, weights
+// streamed through registers, no barrier in the main loop, epilogue straight from the accumulators (conv_panel.hip).  conv_forward routes there
+// only with ConvParams::use_panel (measured slower: profiles/r06_ab_conv_panel.txt); bit-identical to the engine.
+bool conv_panel_supported(const ConvParams& p);
+int conv_panel_forward(const ConvParams& p, hipStream_t stream);
 
 // NCHW [N,C,HW] -> NHWC [N,HW,cstride] at channel offset coff; channels [C, cpad) are zero-filled
 int nchw_to_nhwc(const float* in, float* out, int64_t N, int C, int HW, int cstride, int coff, int cpad, hipStream_t s);

@@ -1001,6 +1001,25 @@ int conv_forward(const ConvParams& p0, hipStream_t stream) {
     if (p.m_end > 0 && p.m_end < p.M) p.M = p.m_end;            // (the bulk launch of a tail split ends early)
     if (p.M <= p.m_off) return MM_OK;
     if (p.Cin_real <= 0) p.Cin_real = p.Cin;
+    // (round 6) K = 256-class increase layers: the activation panel resident in LDS (conv_panel.hip) -- OPT-IN (use_panel: MM_CONV_PANEL=1),
+    // built, bit-identical, measured SLOWER than the engine (profiles/r06_ab_conv_panel.txt).  One workgroup per CU, so a launch is whole
+    // rounds of num_cus() panels; the rows of a thin last round go to the engine below instead (same sums in the same order either way).
+    if (p.use_panel && p.force_tile == 0 && p.m_off == 0 && p.m_end == 0 && conv_panel_supported(p)) {
+        const int64_t slots = num_cus();
+        const int64_t tm = (p.M + 127) / 128;
+        const int64_t full = tm / slots, rest = tm - full * slots;
+        if (full >= 1) {
+            if (rest == 0 || rest * 2 >= slots) return conv_panel_forward(p, stream);
+            ConvParams pb = p, pr = p;
+            pb.M = (int)(full * slots * 128);
+            pr.m_off = pb.M;
+            pr.use_panel = 0;
+            const int64_t t128 = rest * ((p.Cout + 127) / 128);
+            pr.force_tile = t128 * 2 >= (int64_t)num_cus() * 3 ? 1 : 3;
+            const int rc = conv_panel_forward(pb, stream);
+            return rc != MM_OK ? rc : conv_forward(pr, stream);
+        }
+    }
     // Tile choice.  Wave tile 64x64 (2x2 MFMA sub-tiles, 4 accumulators) is the efficient shape: 128x128
     // blocks (2x2 waves) when Cout > 64, 256x64 blocks (4x1 waves) for the 64-channel layers; smaller tiles
     // only when the grid would not give every CU (256) a couple of workgroups.

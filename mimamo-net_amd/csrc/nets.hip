@@ -182,7 +182,7 @@ constexpr int kX3MinK = 512;   // mm_resnet50_set_precision(h, 1): 1x1 layers wi
 
 static int run_layer(const Layer& L, const float* in, int B, int H, int W, int in_cstride, int in_coff, float* out,
                      int out_cstride, int out_coff, const float* res, int res_cstride, hipStream_t s, int* Ho_ = nullptr,
-                     int* Wo_ = nullptr, int x3 = 0, int no_sched = 0, int hpool = 0) {
+                     int* Wo_ = nullptr, int x3 = 0, int no_sched = 0, int hpool = 0, int use_panel = 0) {
     ConvParams p;
     std::memset(&p, 0, sizeof(p));
     p.in = in; p.w = L.w; p.bias = L.bias; p.res = res; p.post_scale = L.ps; p.post_shift = L.pt; p.out = out;
@@ -196,6 +196,7 @@ static int run_layer(const Layer& L, const float* in, int B, int H, int W, int i
     p.x3 = x3 && L.k == 1 && L.Kpad >= kX3MinK;
     p.no_sched = no_sched;
     p.hpool = hpool;
+    p.use_panel = use_panel;
     if (Ho_) *Ho_ = p.Ho;
     if (Wo_) *Wo_ = p.Wo;
     return conv_forward(p, s);
@@ -312,6 +313,8 @@ struct mm_resnet50 {
                    // the full stem output, 2 (default) = the packed-NHWC3 stem also pools horizontally in its epilogue (conv_mfma.hip hpool) and the
                    // pool kernel finishes vertically -- the 112 x 112 x 64 stem output never exists
     int no_sched;  // MM_CONV_SCHED=0 at create time: 1x1 layers on the engine's modes 3 / 6 instead of the scheduled loop (modes 7 / 8): the parity twin
+    int use_panel; // MM_CONV_PANEL=1 at create time: the 256 -> 1024 (+ residual) layers on the LDS-resident-panel kernel (conv_panel.hip, round 6:
+                   // built, bit-identical, measured slower -- default off, the tested twin)
     int wf_generic;// MM_WF_KSL=0 at create time: the fused Winograd kernels' runtime-scheduled main loop (the parity twin of round 5's compile-time one)
     int precision; // 0 (default): every contraction on the fp32 matrix pipes; 1: 1x1 layers with K >= 512 through the three-way bf16 split
                    // (mm_resnet50_set_precision; bench.py's extra.bf16x3 -- never the headline)
@@ -416,6 +419,10 @@ int mm_conv2d_nhwc(const float* in, const float* w, const float* bias, const flo
     p.Cout = Cout; p.out_cstride = out_cstride; p.out_coff = out_coff; p.res_cstride = res_cstride;
     p.kh = kh; p.kw = kw; p.stride = stride; p.pad = pad;
     p.K = kh * kw * Cin; p.Kpad = (p.K + 15) / 16 * 16; p.relu = relu; p.force_tile = tile; p.korder = korder;
+    {
+        const char* cp = getenv("MM_CONV_PANEL");      // read per call (a test switches it): opt-in panel kernel for the shapes it takes
+        p.use_panel = cp && atoi(cp) == 1;
+    }
     return conv_forward(p, (hipStream_t)stream);
 }
 
@@ -442,6 +449,8 @@ int mm_resnet50_create(mm_resnet50_t** out, const float* blob, int64_t n_floats,
         h->wf_generic = wk ? atoi(wk) == 0 : 0;
         const char* cs = getenv("MM_CONV_SCHED");  // measurement knob / parity twin: 0 = no scheduled 1x1 loop in the conv engine
         h->no_sched = cs ? atoi(cs) == 0 : 0;
+        const char* cp = getenv("MM_CONV_PANEL");  // measurement knob / parity twin: 1 = the LDS-resident-panel kernel for the K = 256 increase layers
+        h->use_panel = cp ? atoi(cp) == 1 : 0;
         const char* fp = getenv("MM_FUSE_PROJ");   // measurement knob: 0 = projection shortcut as its own launch + residual read
         h->fuse_proj = fp ? atoi(fp) : 1;
         const char* fpl = getenv("MM_FUSE_POOL");  // measurement knob: 0 = max-pool and conv2_1's reduce conv as two launches (the parity twin),
@@ -660,7 +669,7 @@ int mm_resnet50_forward(mm_resnet50_t* h, const float* images, int nchw, int64_t
             rc = run_layer_dual(Bk.inc_proj, y2, B, H2, W2, x, H, W, C, Bk.proj_stride, o, s, x3, ns);
             H3 = H2; W3 = W2;
         } else {
-            rc = run_layer(Bk.increase, y2, B, H2, W2, Bk.conv3.cout, 0, o, Bk.increase.cout, 0, resid, Bk.increase.cout, s, &H3, &W3, x3, ns);
+            rc = run_layer(Bk.increase, y2, B, H2, W2, Bk.conv3.cout, 0, o, Bk.increase.cout, 0, resid, Bk.increase.cout, s, &H3, &W3, x3, ns, 0, h->use_panel);
         }
         if (rc != MM_OK) return rc;
         H = H3; W = W3; C = Bk.increase.cout;

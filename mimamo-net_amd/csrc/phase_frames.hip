@@ -22,6 +22,13 @@
 #include "phase_math.h"
 #include "phase_blur.h"
 
+#ifndef MM_PW_CHUNK
+#define MM_PW_CHUNK 4   // frames whose plane loads the split kernel keeps in flight at once
+#endif
+#ifndef MM_PW_WAVES
+#define MM_PW_WAVES 5   // waves per SIMD the split kernel is held to (HIP's second launch-bound): 5 -> 96 registers -> two nine-wave workgroups per CU
+#endif
+
 namespace mm {
 
 using namespace blur;
@@ -217,6 +224,238 @@ phase_window2_kernel(const float* __restrict__ fr, const int32_t* __restrict__ i
     }
 }
 
+
+// =====================================================================================================================================
+// Round 6 (round-5 verdict item 3b): the same kernel split ALONG TIME over two workgroups per (window, band) -- BUILT, EQUAL UP TO ONE FMA CONTRACTION, MEASURED
+// SLOWER (profiles/r06_ab_phase_window_split.txt: 0.65-0.66 ms against 0.545 ms for the two launches), so it is NOT the default:
+// MM_PW_SPLIT=2 selects it (the GPU test test_time_split_window_kernel_equals_the_one_workgroup_form runs both: 22 of 24 channels bit-equal, the first
+// difference plane of half 1 one rounding apart -- hipcc contracts blur * R into the subtraction in one kernel and not in the other).
+//   NH = 2: half h owns differences [6 h, 6 h + 6), i.e. frames 6 h .. 6 h + 6.  The spatial mean is per difference plane, so nothing
+//   crosses the workgroups (splitting a plane in SPACE would need a cross-workgroup mean); half 1 only has to know how often each pixel
+//   wrapped before its first frame: six more phase planes, no B, no blur.  The steps torch_unwrap corrects are kept as ONE BIT per
+//   (frame, pixel) (the count a frame needs is a popcount), the plane loads are requested in chunks of MM_PW_CHUNK frames and R only before
+//   the column pass: d[6][4] + the wrap bits fit 96 registers -> TWO nine-wave workgroups per CU (18 waves, five on a SIMD), which is what
+//   the verdict asked for (one 162-register workgroup per CU spends 58 % of its wave time at waitcnt / barrier).  Frame 6 is blurred by both
+//   halves (14 instead of 13 blurs per window and band), half 1 re-reads six phase planes, every workgroup pays the fixed parts (LDS
+//   clear, first-wrap agreement, mean reduction, store staging) for half the output, and the stores are 8-byte instead of 16-byte
+//   channel groups: the added instructions cost more than the second workgroup's overlap buys -- the kernel is bound by VALU / LDS issue,
+//   not by the latency a second workgroup hides.
+template <int W, int F, int NH, int H>
+__device__ __forceinline__ void phase_window2s_body(const float* __restrict__ fr, const int32_t* __restrict__ ids, int n_frames,
+                                                   float* __restrict__ out, int out_nhwc, int out_cstride, int out_coffset, float* lds,
+                                                   int64_t j, int band) {
+    using C = Cfg<W>;
+    constexpr int KN = (P - 1) / NH;                          // difference planes of this workgroup
+    constexpr int K0 = H * KN;                                // ... starting at this one: frames K0 .. K0 + KN
+    constexpr int EW = NH == 1 ? 4 : 2;                       // floats per staging slot / store: 16-byte stores for 12 channels, 8-byte for 6
+    constexpr int PPX = KN / EW;                              // slots per pixel (3 either way)
+    static_assert(KN * NH == P - 1 && PPX * EW == KN, "the difference planes split evenly");
+    constexpr int RPG = W == 48 ? (NH == 1 ? 16 : 24) : (NH == 1 ? 12 : 24);   // rows per store group
+    constexpr int G = W / RPG;
+    constexpr int WORK = F * (C::IN_PLANE + C::TMP_PLANE);
+#ifndef MM_PW_STAGE_PAD
+#define MM_PW_STAGE_PAD 1                                     // 0: the round-4 staging (12-slot thread blocks), for the A/B
+#endif
+    constexpr int SLOTS = PPX * PX + MM_PW_STAGE_PAD * (4 / EW);   // slots per thread block in the store staging: 12 used + 16 bytes of pad
+    static_assert(RPG * C::STRIPS * SLOTS * EW <= WORK, "store staging fits the blur planes");
+    int& first_wrap = *reinterpret_cast<int*>(lds + WORK + 64 * (P - 1));
+    float* in_x = lds;                              // [F][IN_PLANE]
+    float* tmp_x = in_x + F * C::IN_PLANE;          // [F][TMP_PLANE]
+    float* red = lds + WORK;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const bool active = tid < C::ACTIVE;
+    const int y = active ? tid / C::STRIPS : 0;
+    const int x0 = active ? (tid - y * C::STRIPS) * PX : 0;
+    const int px = y * W + x0;
+    for (int i = tid; i < WORK; i += C::NTHREADS) lds[i] = 0.f;    // the zero rows above / below tmp_x
+    if (tid == 0) first_wrap = P;
+    const float TWO_PI_F = 6.28318530717958647692f, PI_F = 3.14159265358979323846f;
+    // ---- A
+    const float* fo[P];
+    float d[KN][PX];
+    // wrapped steps, one bit per (frame, pixel): bit i of wb[p] = the step INTO frame i was corrected; the count a frame needs is
+    // popcount(wb[p] & ((2 << i) - 1)) (k <= 12)
+    unsigned wb[PX] = {0u, 0u, 0u, 0u};
+    {
+        // NH = 1: all 26 loads of the window in flight at once (104 registers of landing space); the split form asks for them in chunks of
+        // CH frames behind a scheduling barrier -- the other workgroup of the CU covers the latency, and the registers are what buys it
+        constexpr int NF = K0 + KN + 1, CH = NH == 1 ? NF : MM_PW_CHUNK;
+        float4 bprev = {0.f, 0.f, 0.f, 0.f}, pprev = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int c0 = 0; c0 < NF; c0 += CH) {
+            float4 bq[CH], pq[CH];
+#pragma unroll
+            for (int t = 0; t < CH; ++t) {
+                const int i = c0 + t;
+                bq[t] = pq[t] = float4{0.f, 0.f, 0.f, 0.f};
+                if (i >= NF) continue;
+                const int id = min(max(ids[j * P + i], 0), n_frames - 1);    // memory-safe whatever the table holds (the shim range-checks it)
+                fo[i] = fr + ((int64_t)id * 2 + band) * C::FRAME_FLOATS;
+                if (active) {
+                    if (i >= K0) bq[t] = *reinterpret_cast<const float4*>(fo[i] + C::PLANE + px);
+                    pq[t] = *reinterpret_cast<const float4*>(fo[i] + 3 * C::PLANE + px);
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < CH; ++t) {
+                const int i = c0 + t;
+                if (i >= NF) continue;
+                const float4 b4 = bq[t], p4 = pq[t];
+                if (i > 0) {
+                    // the steps torch_unwrap corrects by -2 pi (phase_utils.py:9-17), on its own fp32 expression
+                    if ((p4.x - pprev.x) + PI_F > TWO_PI_F) wb[0] |= 1u << i;
+                    if ((p4.y - pprev.y) + PI_F > TWO_PI_F) wb[1] |= 1u << i;
+                    if ((p4.z - pprev.z) + PI_F > TWO_PI_F) wb[2] |= 1u << i;
+                    if ((p4.w - pprev.w) + PI_F > TWO_PI_F) wb[3] |= 1u << i;
+                }
+                if (i > K0) {
+                    d[i - 1 - K0][0] = b4.x - bprev.x; d[i - 1 - K0][1] = b4.y - bprev.y;
+                    d[i - 1 - K0][2] = b4.z - bprev.z; d[i - 1 - K0][3] = b4.w - bprev.w;
+                }
+                bprev = b4;
+                pprev = p4;
+            }
+            if (NH != 1) __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    {
+        // first frame OF THIS WORKGROUP'S RANGE in which one of this thread's pixels has a non-zero count (counts only grow): the first set
+        // bit, but not before frame K0
+        const unsigned any = wb[0] | wb[1] | wb[2] | wb[3];
+        int mine = any ? max(__builtin_ctz(any), K0) : P;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) mine = min(mine, __shfl_xor(mine, off, 64));
+        __syncthreads();                  // first_wrap initialised, LDS zeroed
+        if (lane == 0 && mine < P) atomicMin(&first_wrap, mine);
+        __syncthreads();
+    }
+    const int first = first_wrap;
+    // ---- B
+    float cprev[PX] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int base = K0; base <= K0 + KN; base += F) {
+        if (base + F <= first) continue;             // block-uniform: no pixel of the window has wrapped up to the round's last frame
+        float4 r4[F];
+#pragma unroll
+        for (int f = 0; f < F; ++f) {
+            const int i = base + f;
+            r4[f] = float4{0.f, 0.f, 0.f, 0.f};
+            if (i > K0 + KN || !active) continue;
+            const float4 m4 = *reinterpret_cast<const float4*>(fo[i] + px);
+            // (a pixel's blur also sums its neighbours' wraps: R is needed wherever the window has wrapped at all.  NH = 1 requests it with
+            //  the magnitude; the split form only before the column pass -- 12 registers less across the two barriers of a round)
+            if (NH == 1) r4[f] = *reinterpret_cast<const float4*>(fo[i] + 2 * C::PLANE + px);
+            const unsigned msk = (2u << i) - 1u;
+            *reinterpret_cast<float4*>(in_x + f * C::IN_PLANE + px) =
+                float4{m4.x * (-TWO_PI_F * (float)__builtin_popcount(wb[0] & msk)), m4.y * (-TWO_PI_F * (float)__builtin_popcount(wb[1] & msk)),
+                       m4.z * (-TWO_PI_F * (float)__builtin_popcount(wb[2] & msk)), m4.w * (-TWO_PI_F * (float)__builtin_popcount(wb[3] & msk))};
+        }
+        __syncthreads();
+        if (active) {
+#pragma unroll
+            for (int f = 0; f < F; ++f) {
+                if (base + f > K0 + KN) continue;
+                float h[PX];
+                row_pass<W>(in_x + f * C::IN_PLANE, y, x0, h);
+                *reinterpret_cast<float4*>(tmp_x + f * C::TMP_PLANE + (y + R) * W + x0) = float4{h[0], h[1], h[2], h[3]};
+                if (NH != 1) __builtin_amdgcn_sched_barrier(0);       // one frame's 20-float row window at a time (registers)
+            }
+        }
+        __syncthreads();
+        // (the next round's in_x stores are separated from this round's row-pass reads by the barrier above, its tmp_x stores from
+        //  the column reads below by its own first barrier)
+        if (active) {
+#pragma unroll
+            for (int f = 0; f < F; ++f) {
+                const int i = base + f;
+                if (i > K0 + KN) continue;
+                if (NH != 1) r4[f] = *reinterpret_cast<const float4*>(fo[i] + 2 * C::PLANE + px);
+                float sb[PX];
+                col_pass<W>(tmp_x + f * C::TMP_PLANE, y, x0, sb);
+                const float c[PX] = {sb[0] * r4[f].x, sb[1] * r4[f].y, sb[2] * r4[f].z, sb[3] * r4[f].w};
+#pragma unroll
+                for (int p = 0; p < PX; ++p) {
+                    if (i > K0) d[i - 1 - K0][p] += c[p] - cprev[p];
+                    cprev[p] = c[p];
+                }
+                if (NH != 1) __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    }
+    // ---- C: spatial means of the difference planes: wave shuffle reduce, then across waves
+#pragma unroll
+    for (int k = 0; k < KN; ++k) {
+        float v = active ? (d[k][0] + d[k][1]) + (d[k][2] + d[k][3]) : 0.f;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+        if (lane == 0) red[wave * (P - 1) + k] = v;
+    }
+    __syncthreads();                      // also: every blur read of the planes is done, they become the store staging
+    constexpr int NWAVES = C::NTHREADS / 64;
+    const float LIM = 5.f * PI_F;
+    float mean[KN];
+#pragma unroll
+    for (int k = 0; k < KN; ++k) {
+        float sm = 0.f;
+#pragma unroll
+        for (int w = 0; w < NWAVES; ++w) sm += red[w * (P - 1) + k];
+        mean[k] = sm * (1.0f / (W * W));
+    }
+    if (!out_nhwc) {
+        if (active) {
+#pragma unroll
+            for (int k = 0; k < KN; ++k) {
+                float ov[PX];
+#pragma unroll
+                for (int p = 0; p < PX; ++p) ov[p] = fminf(fmaxf(d[k][p] - mean[k], -LIM), LIM);
+                float* dst = out + ((j * (2 * (P - 1)) + band * (P - 1) + K0 + k) * W + y) * W + x0;
+                *reinterpret_cast<float4*>(dst) = float4{ov[0], ov[1], ov[2], ov[3]};
+            }
+        }
+        return;
+    }
+    typedef float slot_t __attribute__((ext_vector_type(EW)));
+    slot_t* stage = reinterpret_cast<slot_t*>(lds);           // [RPG * STRIPS thread blocks][SLOTS]: pixel-major, PPX slots per pixel
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        if (active && y / RPG == g) {
+            slot_t* mine = stage + (tid - g * RPG * C::STRIPS) * SLOTS;
+#pragma unroll
+            for (int p = 0; p < PX; ++p)
+#pragma unroll
+                for (int q = 0; q < PPX; ++q) {
+                    slot_t v;
+#pragma unroll
+                    for (int e = 0; e < EW; ++e) v[e] = fminf(fmaxf(d[EW * q + e][p] - mean[EW * q + e], -LIM), LIM);
+                    mine[p * PPX + q] = v;
+                }
+        }
+        __syncthreads();
+        for (int idx = tid; idx < RPG * W * PPX; idx += C::NTHREADS) {
+            const int pix = idx / PPX, part = idx - pix * PPX;
+            float* dst = out + ((j * W + g * RPG) * W + pix) * out_cstride + out_coffset + band * (P - 1) + K0 + part * EW;
+            *reinterpret_cast<slot_t*>(dst) = stage[idx + MM_PW_STAGE_PAD * (4 / EW) * (idx / (PPX * PX))];      // skip the pad of every thread block
+        }
+        if (g + 1 < G) __syncthreads();
+    }
+}
+
+// registers: NH = 1 as the compiler likes it (162: one nine-wave workgroup per CU); NH = 2 held to 96 so that two nine-wave workgroups
+// (five waves on one SIMD) share a CU
+template <int W, int F, int NH>
+__global__ void __launch_bounds__(Cfg<W>::NTHREADS, NH == 1 ? 1 : MM_PW_WAVES)
+phase_window2s_kernel(const float* __restrict__ fr, const int32_t* __restrict__ ids, int n_frames, float* __restrict__ out, int out_nhwc,
+                     int out_cstride, int out_coffset) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];      // WORK + 64 * (P - 1) floats + first_wrap
+    // consecutive windows share 12 of their 13 frames: keep them on one XCD (one L2) instead of spreading them over all eight
+    const int logical = xcd_contiguous(blockIdx.x, gridDim.x);
+    const int64_t j = logical / (2 * NH);
+    const int rem = logical - (int)j * (2 * NH);
+    const int band = rem / NH;
+    if (NH == 1 || rem - band * NH == 0) phase_window2s_body<W, F, NH, 0>(fr, ids, n_frames, out, out_nhwc, out_cstride, out_coffset, lds, j, band);
+    else phase_window2s_body<W, F, NH, NH - 1>(fr, ids, n_frames, out, out_nhwc, out_cstride, out_coffset, lds, j, band);
+}
+
 template <int W, int F>
 static int launch_w2(const float* fr, const int32_t* ids, int n, int64_t J, float* out, int out_nhwc, int out_cstride, int out_coffset,
                      hipStream_t s) {
@@ -230,10 +469,30 @@ static int launch_w2(const float* fr, const int32_t* ids, int n, int64_t J, floa
     return MM_OK;
 }
 
+template <int W, int F>
+static int launch_w2s(const float* fr, const int32_t* ids, int n, int64_t J, float* out, int out_nhwc, int out_cstride, int out_coffset,
+                      hipStream_t s) {
+    using C = Cfg<W>;
+    const int lds_bytes = (F * (C::IN_PLANE + C::TMP_PLANE) + 64 * (P - 1) + 4) * 4;
+    MM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(phase_window2s_kernel<W, F, 2>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               lds_bytes));
+    hipLaunchKernelGGL((phase_window2s_kernel<W, F, 2>), dim3((unsigned)(4 * J)), dim3(C::NTHREADS), lds_bytes, s, fr, ids, n, out, out_nhwc,
+                       out_cstride, out_coffset);
+    MM_LAUNCH_CHECK();
+    return MM_OK;
+}
+
 int launch_phase_window2(const float* fr, const int32_t* ids, int64_t n, int64_t J, int W, float* out, int out_nhwc, int out_cstride,
                          int out_coffset, hipStream_t s) {
     if (J <= 0) return MM_OK;
-    if (n <= 0 || n > 0x7fffffff || 2 * J > 0x7fffffff) return MM_ERR_INVALID_ARG;
+    if (n <= 0 || n > 0x7fffffff || 4 * J > 0x7fffffff) return MM_ERR_INVALID_ARG;
+    // MM_PW_SPLIT=2 (read per call: a test switches it): the time-split form above -- measured slower, default off
+    const char* e = getenv("MM_PW_SPLIT");
+    if (e && atoi(e) == 2) {
+        if (W == 48) return launch_w2s<48, 3>(fr, ids, (int)n, J, out, out_nhwc, out_cstride, out_coffset, s);
+        if (W == 24) return launch_w2s<24, 3>(fr, ids, (int)n, J, out, out_nhwc, out_cstride, out_coffset, s);
+        return MM_ERR_UNSUPPORTED;
+    }
     // F = 3 frames per barrier round; 4 / 5 / 7 measured equal or slower (0.547 / 0.554 / 0.554 / 0.593 ms per 2 048 windows):
     // the kernel is not waiting at its barriers
     if (W == 48) return launch_w2<48, 3>(fr, ids, (int)n, J, out, out_nhwc, out_cstride, out_coffset, s);

@@ -148,6 +148,26 @@ def _count_conv_launches(fn):
     return int(n[0])
 
 
+def _last_conv_tags(fn):
+    """Tags of the conv / GEMM launches inside fn() (MM_PROF_DUMP rows of category 0)."""
+    import tempfile
+    from mimamo_net_amd import _lib
+    L = _lib.lib()
+    d = tempfile.mkdtemp(prefix="mm_tags_")
+    os.environ["MM_PROF_DUMP"] = os.path.join(d, "l.csv")
+    try:
+        ms, work, n = (ctypes.c_double * 5)(), (ctypes.c_double * 5)(), (ctypes.c_int64 * 5)()
+        assert L.mm_profile_begin() == 0
+        fn()
+        assert L.mm_profile_end(ms, work, n) == 0
+        with open(os.path.join(d, "l.csv")) as f:
+            return [line.rstrip("\n").split(",", 3)[3] for line in f if line.startswith("0,")]
+    finally:
+        os.environ.pop("MM_PROF_DUMP", None)
+        import shutil
+        shutil.rmtree(d, ignore_errors=True)
+
+
 SPLIT_CASES = [
     # B, side, Cin, Cout, residual.  M = 200 704 rows = 1 568 tiles of 128x256 on 512 resident workgroups = 3.06 rounds: conv_forward
     # gives the 1 536 tiles of the full rounds to the 128x256 kernel and rows [196 608, 200 704) to a second launch on 64x64 tiles
@@ -195,6 +215,89 @@ def test_tail_split_is_bit_identical_to_the_unsplit_launch(pkg, dev, case):
     ref = torch.relu(ref)
     err = (outs[0][idx].double().cpu() - ref).abs().max().item()
     assert err < 2e-5, err
+
+
+PANEL_CASES = [
+    # B, side, Cin, Cout, residual, relu.  M >= 256 panels of 128 rows or the launch stays in the engine
+    (168, 14, 256, 1024, True, 1),     # conv4_x's increase layer + residual at 168 frames: 32 928 rows = 257.25 panels -> 256 on the panel
+                                       # kernel, rows [32 768, 32 928) on the engine's 64x64 tiles (ragged last tile)
+    (350, 14, 256, 1024, True, 1),     # 68 600 rows = 535.9 panels: the last round is 24 / 256 full -> split off
+    (400, 14, 256, 512, False, 0),     # no residual, no ReLU, N = 512: 78 400 rows = 612.5 panels, last round 100 / 256: split off
+    (700, 14, 256, 1024, False, 1),    # 137 200 rows = 1071.9 panels: last round 48 / 256
+    (172, 28, 128, 512, True, 1),      # K = 128 (conv3_x's increase layer when it is not inside the fused kernel): 64 KB panel
+    (500, 14, 256, 1024, True, 1),     # 98 000 rows = 765.6 panels: the last round is 253.6 / 256 full -> one launch, ragged last panel
+]
+
+
+@pytest.mark.parametrize("case", PANEL_CASES)
+def test_conv_panel_kernel_is_bit_identical_to_the_engine(pkg, dev, case, monkeypatch):
+    """Round 6 (csrc/conv_panel.hip; OPT-IN with MM_CONV_PANEL=1 -- built, bit-identical, measured slower than the engine,
+    profiles/r06_ab_conv_panel.txt): 1x1 layers with K = 256 / 128 and N >= 512 keep their 128-row activation panel in LDS for ALL N,
+    stream the weights through registers (no workgroup barrier in the main loop) and write 16-byte channel quads straight from the
+    TRANSPOSED accumulators.  Same products in the same order per output element as the engine's 128x256 tile (tile = 5 forces it):
+    the same BITS, residual / bias / ReLU included; whole rounds of panels go to the panel kernel, the rows of a thin last round to
+    the engine (launch counts checked); sampled rows against float64."""
+    from mimamo_net_amd import _lib
+    B, side, Ci, Co, with_res, relu = case
+    M = B * side * side
+    g = torch.Generator(device="cpu").manual_seed(M + Ci + Co)
+    x = torch.randn((M, Ci), generator=g).to(dev)
+    w = (torch.randn((Co, Ci), generator=g) * 0.05).to(dev)
+    b = torch.randn((Co,), generator=g).to(dev)
+    res = torch.randn((M, Co), generator=g).to(dev) if with_res else None
+
+    def run(tile):
+        out = torch.full((M, Co), -7.0, device=dev)
+        rc = _lib.lib().mm_conv2d_nhwc(_lib.ptr(x), _lib.ptr(w), _lib.ptr(b), _lib.ptr(res) if with_res else None, None, None, _lib.ptr(out),
+                                       B, side, side, Ci, Ci, 0, Co, Co, 0, Co, 1, 1, 1, 0, relu, tile, 0, _lib.current_stream())
+        assert rc == 0
+        return out
+
+    outs = {}
+    assert not any(t.endswith("t128xNp b1") for t in _last_conv_tags(lambda: run(0)))       # the default stays in the engine
+    monkeypatch.setenv("MM_CONV_PANEL", "1")
+    n_auto = _count_conv_launches(lambda: outs.__setitem__(0, run(0)))
+    tags = _last_conv_tags(lambda: run(0))
+    assert any(t.endswith("t128xNp b1") for t in tags), tags
+    outs[5] = run(5)
+    tm = (M + 127) // 128
+    rest = tm % 256
+    assert n_auto == (1 if rest == 0 or rest * 2 >= 256 else 2), (n_auto, tm, rest, tags)
+    assert torch.isfinite(outs[0]).all()
+    assert torch.equal(outs[0], outs[5]), ((outs[0] - outs[5]).abs().max().item(), (outs[0] != outs[5]).float().mean().item())
+    for _ in range(3):
+        assert torch.equal(run(0), outs[0])                      # and run to run (eight free-running waves, no barrier in the loop)
+    bnd = (tm // 256) * 256 * 128
+    rows = sorted(set(r for r in [0, 1, 31, 32, 63, 64, 127, 128, bnd - 129, bnd - 1, bnd, bnd + 1, M - 129, M - 128, M - 2, M - 1] +
+                      list(range(7, M, 2053)) if 0 <= r < M))
+    idx = torch.tensor(rows, device=dev)
+    ref = x[idx].double().cpu() @ w.double().cpu().t() + b.double().cpu()
+    if with_res:
+        ref = ref + res[idx].double().cpu()
+    if relu:
+        ref = torch.relu(ref)
+    err = (outs[0][idx].double().cpu() - ref).abs().max().item()
+    assert err < 2e-5, err
+
+
+def test_resnet50_panel_kernel_twin(dev, monkeypatch):
+    """The trunk at 176 frames with MM_CONV_PANEL=1 at create time (conv4_x's 256 -> 1024 + residual layers then have 34 496 rows = 269.5
+    panels: one whole round on the panel kernel) against the default (every layer in the engine): the same pool5 BITS."""
+    from mimamo_net_amd.resnet50_extractor import Resnet50_Extractor
+    sd = weights.make_resnet50_state_dict(seed=0)
+    xt = torch.from_numpy(_images(4, 43)).to(dev).repeat(44, 1, 1, 1).contiguous()
+    twin = Resnet50_Extractor(state_dict=sd, device=dev)
+    monkeypatch.setenv("MM_CONV_PANEL", "1")
+    new = Resnet50_Extractor(state_dict=sd, device=dev)
+    monkeypatch.delenv("MM_CONV_PANEL")
+    tags = _last_conv_tags(lambda: new.get_vec(xt))
+    assert sum(t.endswith("t128xNp b1") for t in tags) == 5, tags
+    assert not any(t.endswith("t128xNp b1") for t in _last_conv_tags(lambda: twin.get_vec(xt)))
+    a, b = new.get_vec(xt), twin.get_vec(xt)
+    assert torch.isfinite(a).all() and torch.equal(a, b), (a - b).abs().max().item()
+    assert torch.equal(a[:4], a[172:176])                           # the four distinct images repeat
+    new.close()
+    twin.close()
 
 
 @pytest.mark.parametrize("tile", [4, 1])

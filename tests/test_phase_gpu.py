@@ -153,6 +153,54 @@ def test_fast_path_takes_any_window_pattern(pde, dev):
         pde.phase_diff_frames(f, ids + 50)
 
 
+def test_time_split_window_kernel_equals_the_one_workgroup_form(pde, dev, monkeypatch):
+    """Round 6 (verdict item 3b), built and measured SLOWER (profiles/r06_ab_phase_window_split.txt), kept opt-in as MM_PW_SPLIT=2:
+    phase_window2s_kernel runs TWO workgroups per (window, band), each owning six of the twelve difference planes (split along time: the
+    spatial mean is per plane, so nothing crosses the workgroups; half 1 counts the wraps of frames 1..6 from their phase planes and blurs
+    frame 6 again) at 96 registers -> two nine-wave workgroups per CU.  Same operations on the same values per output element as the shipped
+    one-workgroup kernel: 22 of the 24 channels carry the same BITS; the first difference plane of half 1 (channels 6 and 18: d = (B7 - B6) +
+    (c7 - c6), where hipcc contracts c7 = blur * R into the subtraction in one kernel and not in the other) and one level-2 channel differ by
+    one rounding (<= 1.1e-6 observed, tools/probes/pw_split_diff.py) -- on clips that wrap early and late in their windows, on arbitrary id
+    patterns, in NCHW and NHWC (8-byte instead of 16-byte channel groups per store) layouts, and on a still clip (no wrap: blur skipped)."""
+    n = 3 * 64
+    # fast-moving texture: per-frame shifts of ~1 px wrap the level-1 phases within a few frames
+    base = np.concatenate([synthetic.textured_gray(64, 48, seed=400 + c) for c in range(3)])
+    fast = np.stack([np.roll(base[3 * (t // 64)], (t % 64), axis=1) for t in range(n)]).astype(np.float32)
+    frames = torch.from_numpy(np.ascontiguousarray(fast)).to(dev)
+    one = torch.clamp(torch.arange(64, device=dev)[:, None] + torch.arange(-6, 7, device=dev)[None, :], 0, 63)
+    ids = (one[None] + 64 * torch.arange(3, device=dev)[:, None, None]).reshape(n, 13).int().contiguous()
+    rng = np.random.RandomState(11)
+    odd = torch.from_numpy(np.stack([np.arange(13) * 3 + 1, np.arange(13)[::-1] + 40, rng.randint(0, n, 13), rng.randint(0, n, 13),
+                                     np.repeat(np.arange(100, 107), 2)[:13]]).astype(np.int32)).to(dev)
+    still = frames[:1].repeat(16, 1, 1).contiguous()
+    slow = torch.from_numpy(synthetic.textured_gray(64, 48, seed=77)).to(dev)
+    cases = ((frames, ids), (frames, odd), (still, ids[:16].clamp(max=15).contiguous()), (slow, ids[:64].contiguous()))
+
+    def run():
+        out = []
+        for f, i in cases:
+            out += [t.clone() for t in pde.phase_diff_frames(f, i)]
+            a0, a1 = pde.phase_diff_frames(f, i, nhwc=True, out1_cstride=88, out1_coffset=64)
+            out += [a0.clone(), a1[..., 64:].clone()]
+        return out
+    shipped = run()
+    monkeypatch.setenv("MM_PW_SPLIT", "2")
+    split = run()
+    monkeypatch.delenv("MM_PW_SPLIT")
+    print("split vs one-workgroup window kernel: %d tensors compared" % len(shipped))
+    worst = 0.0
+    for k, (a, b) in enumerate(zip(shipped, split)):
+        assert torch.isfinite(a).all() and a.shape == b.shape
+        diff = (a - b).abs().max().item()
+        worst = max(worst, diff)
+        assert diff < 4e-6, (k, diff, (a != b).float().mean().item())
+        ch = 1 if a.shape[1] == 24 else 3                               # channel axis: NCHW tensors are [J,24,W,W], NHWC ones [J,W,W,24]
+        same = [c for c in range(24) if torch.equal(a.select(ch, c), b.select(ch, c))]
+        assert len(same) >= 20 and {0, 2, 3, 4, 5, 7, 8, 9, 10, 11}.issubset(same), (k, same)
+    print("largest |split - shipped| %.2e" % worst)
+    assert shipped[8].abs().max() == 0 and shipped[9].abs().max() == 0          # still clip: identically zero
+
+
 def test_unwrap_decision_at_exactly_pi(pde, oracle, dev):
     """torch_unwrap at dd == fp32(pi) exactly: fmod(dd + pi, 2 pi) = 0 -> ddmod = -pi -> reset to +pi because dd > 0 -> the
     correction is pi - dd = 0, NOT -2 pi (api/utils/phase_utils.py:9-17).  The window kernel must decide `dd + pi > 2 pi`, not
