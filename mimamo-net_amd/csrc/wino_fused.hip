@@ -34,6 +34,14 @@
 namespace mm {
 
 typedef float f32x4v __attribute__((ext_vector_type(4)));
+#ifndef MM_WF_NT_STORES
+#define MM_WF_NT_STORES 1   // 0: the INC epilogues' 64-byte-per-pixel stores WITHOUT the non-temporal hint (A/B knob, round 6)
+#endif
+// the INC epilogues' output stores: four consecutive channels of one pixel per lane, 64 contiguous bytes per pixel and instruction
+__device__ __forceinline__ void inc_store(const f32x4v& v, float* dst) {
+    if (MM_WF_NT_STORES) __builtin_nontemporal_store(v, reinterpret_cast<f32x4v*>(dst));
+    else *reinterpret_cast<f32x4v*>(dst) = v;
+}
 
 struct WinoFusedParams {
     const float* V;      // [36][ntile][K]
@@ -693,7 +701,7 @@ wino_fused_kernel(const WinoFusedParams p) {
                     if (tok && 4 * ty + pp < p.H && 4 * tx + qq < p.W) {
                         float* op = obase + ((int64_t)pp * p.W + qq) * p.C2;
 #pragma unroll
-                        for (int j = 0; j < 2; ++j) __builtin_nontemporal_store(acc[j], reinterpret_cast<f32x4v*>(op + j * 16));
+                        for (int j = 0; j < 2; ++j) inc_store(acc[j], op + j * 16);
                     }
                 }
             }
@@ -740,7 +748,7 @@ wino_fused_kernel(const WinoFusedParams p) {
                 if (tok && 4 * ty + pp < p.H && 4 * tx + qq < p.W) {
                     float* op = obase + ((int64_t)pp * p.W + qq) * p.C2;
 #pragma unroll
-                    for (int j = 0; j < 2; ++j) __builtin_nontemporal_store(acc[j], reinterpret_cast<f32x4v*>(op + j * 16));
+                    for (int j = 0; j < 2; ++j) inc_store(acc[j], op + j * 16);
                 }
             }
         }
@@ -853,7 +861,7 @@ wino_fused_kernel(const WinoFusedParams p) {
                 if (tok && 4 * ty + pp < p.H && 4 * tx + qq < p.W) {
                     float* op = obase + ((int64_t)pp * p.W + qq) * p.C2;
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) __builtin_nontemporal_store(acc[j], reinterpret_cast<f32x4v*>(op + j * 16));
+                    for (int j = 0; j < 4; ++j) inc_store(acc[j], op + j * 16);
                 }
             }
         }
@@ -1052,7 +1060,7 @@ wino_fused_kernel(const WinoFusedParams p) {
             if (pix_ok && !(abl & 16)) {
                 float* op = obase + ((int64_t)pp * p.W + qq) * p.C2 + h * 64;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) __builtin_nontemporal_store(acc[j], reinterpret_cast<f32x4v*>(op + j * 16));
+                for (int j = 0; j < 4; ++j) inc_store(acc[j], op + j * 16);
             }
             if constexpr (NEXT) {
                 // third GEMM: D[nb] += W3[16 nb + l16][these 64 channels] * x[these 64 channels][tile l16]; x = acc as it stands
