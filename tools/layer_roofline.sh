@@ -1,7 +1,7 @@
 #!/bin/bash
 # Per-launch limiting roofline (tools/layer_roofline.py): one plain run for the hipEvent times, two rocprofv3 PMC passes for the HBM
-# bytes of every launch.  usage (GPU box): bash tools/layer_roofline.sh [clips]   ->  gpurun_out/r05_layer_table_<clips>clips.txt,
-# gpurun_out/r05_layer_bytes_<clips>clips.json (copy both to profiles/)
+# bytes of every launch.  usage (GPU box): bash tools/layer_roofline.sh [clips]   ->  gpurun_out/r06_layer_table_<clips>clips.txt,
+# gpurun_out/r06_layer_bytes_<clips>clips.json (copy both to profiles/)
 CLIPS=${1:-32}
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 cd /tmp && export TMPDIR=/tmp
@@ -13,5 +13,5 @@ for c in FETCH_SIZE WRITE_SIZE; do
   MM_PROF_DUMP=/tmp/lr_dump_pmc.csv rocprofv3 --pmc $c --kernel-trace --output-format csv -d /tmp/lr_$c -o out -- python $R/tools/layer_table.py $CLIPS 1 > /tmp/lr_$c.log 2>&1 \
       || { tail -5 /tmp/lr_$c.log; exit 1; }
 done
-python $R/tools/layer_roofline.py /tmp/lr_dump_plain.csv /tmp/lr_FETCH_SIZE /tmp/lr_WRITE_SIZE $CLIPS $R/gpurun_out/r05_layer_table_${CLIPS}clips.txt \
-       $R/gpurun_out/r05_layer_bytes_${CLIPS}clips.json
+python $R/tools/layer_roofline.py /tmp/lr_dump_plain.csv /tmp/lr_FETCH_SIZE /tmp/lr_WRITE_SIZE $CLIPS $R/gpurun_out/r06_layer_table_${CLIPS}clips.txt \
+       $R/gpurun_out/r06_layer_bytes_${CLIPS}clips.json

@@ -2,7 +2,7 @@
 # HBM/fabric traffic per bench step from rocprofv3 PMC counters, collected as MI355X_MICROARCH.md prescribes: FETCH_SIZE and
 # WRITE_SIZE in SEPARATE passes (TCC slot budget), --kernel-trace only, FETCH_SIZE doubled (gfx950 reports half the bytes of
 # 16-byte-per-lane streaming reads; checked on a 1x1 conv whose operand read is known).  Writes
-# gpurun_out/r05_conv_traffic_<clips>clips.json and gpurun_out/r05_phase_traffic_<clips>clips.json, each stamped with the hash of
+# gpurun_out/r06_conv_traffic_<clips>clips.json and gpurun_out/r06_phase_traffic_<clips>clips.json, each stamped with the hash of
 # the kernel sources they were measured on (bench.py only quotes a summary whose hash matches).  usage: tools/pmc_traffic.sh [clips]
 CLIPS=${1:-32}
 STEPS=2; WARM=1
@@ -20,6 +20,11 @@ clips, steps, warm, root = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]),
 sys.path.insert(0, root)
 import bench
 nsteps = steps + warm + 2          # + the two single-stream steps of the roofline leg
+for c in ("FETCH_SIZE", "WRITE_SIZE"):   # ... as the profiled run itself reports it (bench.py's line: hot_path_steps_executed)
+    for line in open("/tmp/bt_%s.log" % c):
+        if line.startswith('{"metric"'):
+            got = json.loads(line).get("hot_path_steps_executed")
+            assert got == nsteps, (c, got, nsteps)
 groups = {"conv": ("conv_mfma_kernel", "wino_fused_kernel"), "winograd_transforms": ("wino_in", "wino_out"),
           "pyramid": ("pyramid_kernel", "pyramid_frame_kernel"), "phase_frames_windows": ("phase_window2_kernel",)}
 tot = {g: {} for g in groups}
@@ -40,7 +45,7 @@ conv = dict(common, bytes_per_step=bytes_per_step("conv"), kernels="conv_mfma_ke
             winograd_transforms_bytes_per_step=bytes_per_step("winograd_transforms"))
 phase = dict(common, bytes_per_step=bytes_per_step("pyramid") + bytes_per_step("phase_frames_windows"),
              pyramid_bytes_per_step=bytes_per_step("pyramid"), frames_windows_bytes_per_step=bytes_per_step("phase_frames_windows"))
-json.dump(conv, open(root + "/gpurun_out/r05_conv_traffic_%dclips.json" % clips, "w"), indent=1)
-json.dump(phase, open(root + "/gpurun_out/r05_phase_traffic_%dclips.json" % clips, "w"), indent=1)
+json.dump(conv, open(root + "/gpurun_out/r06_conv_traffic_%dclips.json" % clips, "w"), indent=1)
+json.dump(phase, open(root + "/gpurun_out/r06_phase_traffic_%dclips.json" % clips, "w"), indent=1)
 print(json.dumps(conv)); print(json.dumps(phase))
 PY
