@@ -112,7 +112,23 @@ def test_default_line_has_the_contract_fields():
     # here (and say why); the default 32-clip line carries them (tests/test_host_logic.py checks that profiles/ has the files)
     assert d["roofline"]["mixed_frac"] is None and "note" in d["roofline"]["mixed"]
     ph = d["roofline_phase"]
-    assert ph["floor_mfma_ms"] > ph["floor_hbm_ms"] > 0 and ph["limiting_floor"] == "mfma" and 0 < ph["frac_of_limiting_floor"] < 1
+    assert ph["floor_mfma_ms"] > ph["floor_hbm_ms"] > 0 and 0 < ph["frac_of_limiting_floor"] < 1
+    # round 6: per-kernel floors of the phase stage (HBM, MFMA for the pyramid, VALU issue from the live SQ pass) and their sum; the sustained
+    # clock of the conv launches and the fraction of the MFMA peak at that clock beside the nominal one (null with a reason when the
+    # profiler is not on the box)
+    ks = ph["kernels"]
+    assert set(ks) == {"pyramid_frame", "phase_window2<48>", "phase_window2<24>"}
+    assert ks["pyramid_frame"]["limiter"] == "mfma" and all(k["floor_ms"] > 0 and 0 < k["frac_of_floor"] < 1 for k in ks.values())
+    assert abs(ph["limiting_floor_ms"] - sum(k["floor_ms"] for k in ks.values())) < 1e-9 and "pyramid_frame:mfma" in ph["limiting_floor"]
+    r = d["roofline"]
+    for k in ("sustained_clock_GHz", "mfma_busy_frac", "peak_at_sustained_clock", "frac_at_sustained_clock", "clock_note"):
+        assert k in r, k
+    if r["sustained_clock_GHz"] is not None:
+        assert 1.5 < r["sustained_clock_GHz"] < 4.5 and 0 < r["mfma_busy_frac"] < 1 and r["frac_at_sustained_clock"] > 0
+        assert ks["phase_window2<48>"]["limiter"] == "valu" and ph["floor_valu_ms"] > 0
+    else:
+        assert "no live SQ" in r["clock_note"]
+    assert d["hot_path_steps_executed"] >= 5
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["cpu_model"] and cb["deduplicated"]["value"] > 0
     # round 5: what the CPU figure is made of (library versions, per-stage rates) and the "as tuned" variant beside the reference-faithful one
