@@ -42,6 +42,9 @@ struct ConvParams {
     int no_sched;    // 1: keep modes 3 / 6 for such a layer (the parity twin of the scheduled loop)
     int use_panel;   // 1: a layer conv_panel.hip applies to runs there (MM_CONV_PANEL=1: opt-in, measured slower than the engine -- the tested twin)
     int x3;          // 1: 1x1 layer on the bf16 matrix pipes through a three-way bf16 split of both fp32 operands (conv_mfma.hip X3; `extra` only)
+    const unsigned short* w3;   // (round 6, x3 only) the same weights pre-split into three bf16 planes [3][w3_plane] (bf16x3_split_weights): the 128x256
+    int64_t w3_plane;           // tile then reads the B fragments ready-made (no split of the weights in the loop); null = split in the loop.  Elements
+                                // per plane = batch * Cout * Kpad (a batched launch indexes a plane with w_bstride like `w`)
     // exact division of a row index m < 2^31 by Ho * Wo and by Wo as multiply-high + shift (filled by conv_forward; the emulated 32-bit divisions of
     // the tile prologue were a third of its vector instructions, and vector instructions are matrix time on this chip)
     unsigned div_hw_mul, div_hw_sh, div_wo_mul, div_wo_sh;
@@ -51,6 +54,9 @@ struct ConvParams {
 };
 
 int conv_forward(const ConvParams& p, hipStream_t stream);
+// fp32 weights [n] (n % 16 == 0) -> three bf16 planes [3][n]: x = h + m + l, each the round-to-nearest bf16 of what is left (the split the
+// bf16x3 loop applies to its fragments, applied once)
+int bf16x3_split_weights(const float* w, unsigned short* out, int64_t n, hipStream_t stream);
 // (round 6) 1x1 layers with K = 256 (or 128) and N a multiple of 256, N >= 512, stride 1: the 128-row activation panel resident in LDS, weights
 // streamed through registers, no barrier in the main loop, epilogue straight from the accumulators (conv_panel.hip).  conv_forward routes there
 // only with ConvParams::use_panel (measured slower: profiles/r06_ab_conv_panel.txt); bit-identical to the engine.

@@ -128,9 +128,9 @@ constexpr int CLD = 16;   // LDS row = one 16-float chunk; the four 16-byte slot
 // (the scheduled 1x1 loop of the 128x128 tile would take 188 registers -- every fragment read of a step in flight at once -- where its mode-3
 //  twin's 156 keep three workgroups on a CU: held to three waves per SIMD.  The bf16x3 instantiations are held to the occupancy of their fp32 twins: the eight-wave one needs 133 registers where 128 keep two
 //  workgroups on a CU; the four-wave 128x256 one -- 64x128 wave tiles -- 280 where 256 keep two waves on a SIMD)
-template <int BM, int BN, int WGM, int WGN, int KMODE, bool ABL = false, bool X3 = false>
+template <int BM, int BN, int WGM, int WGN, int KMODE, bool ABL = false, int X3 = 0>
 __global__ void __launch_bounds__(WGM * WGN * 64)
-    __attribute__((amdgpu_waves_per_eu(X3 ? (WGM * WGN == 8 ? 4 : 2) : (KMODE >= 7 && WGM * WGN == 4 && BM * BN == 128 * 128) ? 3 : 1, 8)))
+    __attribute__((amdgpu_waves_per_eu(X3 == 2 ? 2 : X3 ? (WGM * WGN == 8 ? 4 : 2) : (KMODE >= 7 && WGM * WGN == 4 && BM * BN == 128 * 128) ? 3 : 1, 8)))
 conv_mfma_kernel(const ConvParams p) {
     constexpr int NW = WGM * WGN;                     // waves per workgroup: 4, or 8 for the 128x256 tile
     constexpr int TMODE = KMODE == 9 ? 5 : KMODE == 10 ? 2 : KMODE == 11 ? 1 : KMODE;      // the tap walk a scheduled mode takes its offsets from
@@ -147,7 +147,11 @@ conv_mfma_kernel(const ConvParams p) {
     // ds_write instructions are spent on staging.  The staging epilogue re-uses the same bytes (SLD = WN + 4).
     constexpr int NBUF = 3;               // LDS ring: chunk kc is consumed while kc+1 and kc+2 are in flight
     constexpr int STAGE_FLOATS = NW * 32 * (BN / WGN + 4);
-    constexpr int OPER_FLOATS = NBUF * (BM + BN) * CLD;
+    // X3 == 2 (round 6): the weights arrive PRE-SPLIT as three bf16 planes (ConvParams::w3): a row of a ring slot is three times 16 bf16 = 96 B
+    // instead of 16 fp32 = 64 B -- plane-major [slot][plane][BN rows][32 B], lane-linear for the DMA (lane l -> row l >> 1, half l & 1) and for the
+    // fragment reads (lanes = consecutive rows x two 16-byte halves: conflict free without a swizzle)
+    constexpr int BROW = X3 == 2 ? 24 : CLD;      // floats of LDS per B row and ring slot
+    constexpr int OPER_FLOATS = NBUF * (BM * CLD + BN * BROW);
     __shared__ __attribute__((aligned(16))) float lds[OPER_FLOATS > STAGE_FLOATS ? OPER_FLOATS : STAGE_FLOATS];
     float* As = lds;                      // [NBUF][BM][16]
     float* Bs = lds + NBUF * BM * CLD;    // [NBUF][BN][16]
@@ -221,6 +225,18 @@ conv_mfma_kernel(const ConvParams p) {
     for (int it = 0; it < BIT; ++it) {
         const int n = n_base + lrow + it * RPR;
         vb[it] = n < p.Cout ? (unsigned)(n * p.Kpad + kq * 4) * 4u : OOB;
+    }
+    // X3 == 2: one DMA instruction covers 32 rows x 32 B of ONE plane; wave w fetches rows [32 w, 32 w + 32) of each of the three planes
+    unsigned vb3[3] = {OOB, OOB, OOB};
+    __amdgpu_buffer_rsrc_t rsrc_b3 = rsrc_b;
+    if constexpr (X3 == 2) {
+        static_assert(BN == 32 * NW, "one 32-row piece per wave and plane");
+        const int n = n_base + wave * 32 + (lane >> 1);
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl)
+            vb3[pl] = n < p.Cout ? (unsigned)(((int64_t)pl * p.w3_plane + (int64_t)n * p.Kpad + (lane & 1) * 8) * 2) : OOB;
+        rsrc_b3 = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(p.w3) + (int64_t)bz * p.w_bstride, 0,
+                                                    (unsigned)((2 * p.w3_plane + (int64_t)p.Cout * p.Kpad) * 2), 0x00020000);
     }
     // tap state of this lane's k-quad, advanced by one chunk (16) per iteration.  Two K orders:
     //   korder 0:  k = (r*kw + s)*Cin + c              (any Cin % 4 == 0)
@@ -300,6 +316,10 @@ conv_mfma_kernel(const ConvParams p) {
         }
 #pragma unroll
         for (int it = 0; it < BIT; ++it) vb[it] = vb[it] == OOB ? OOB : vb[it] + CBK * 4u;
+        if constexpr (X3 == 2) {
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) vb3[pl] = vb3[pl] == OOB ? OOB : vb3[pl] + CBK * 2u;
+        }
     };
 
     // One chunk = AIT + BIT direct-to-LDS loads per wave, issued from inline asm: hipcc models an LDS-DMA builtin
@@ -307,7 +327,7 @@ conv_mfma_kernel(const ConvParams p) {
     // would expose the full memory latency every chunk.  Hidden in asm, the loads stay in flight across the
     // fragment reads, the MFMAs and the barrier; completion is tracked by hand with counted vmcnt waits (the
     // loop issues no other VMEM instruction).  M0 (LDS base of the 1 KB slab) is written in the same statement.
-    constexpr int NL = AIT + BIT;  // loads per wave per chunk
+    constexpr int NL = AIT + (X3 == 2 ? 3 : BIT);  // loads per wave per chunk
     const unsigned lds_a = (unsigned)(uintptr_t)(__attribute__((address_space(3))) float*)As;
     const unsigned lds_b = (unsigned)(uintptr_t)(__attribute__((address_space(3))) float*)Bs;
     auto dma1 = [&](const __amdgpu_buffer_rsrc_t& rsrc, unsigned voff, unsigned lds_byte) {
@@ -327,8 +347,13 @@ conv_mfma_kernel(const ConvParams p) {
             for (int it = 0; it < AIT; ++it) dma1(rsrc_a, va[it], lds_a + ((buf * BM + (it * NW + wave) * 16) * CLD) * 4);
         }
         ++dchunk;
+        if constexpr (X3 == 2) {
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) dma1(rsrc_b3, vb3[pl], lds_b + (((buf * 3 + pl) * BN + wave * 32) * 32));
+        } else {
 #pragma unroll
         for (int it = 0; it < BIT; ++it) dma1(rsrc_b, vb[it], lds_b + ((buf * BN + (it * NW + wave) * 16) * CLD) * 4);
+        }
     };
 
     f32x16 acc[TM][TN];
@@ -673,10 +698,12 @@ conv_mfma_kernel(const ConvParams p) {
                 fa[i][0] = *reinterpret_cast<const float4*>(As + buf * BM * CLD + fa_off[i][0]);
                 fa[i][1] = *reinterpret_cast<const float4*>(As + buf * BM * CLD + fa_off[i][1]);
             }
+            if constexpr (X3 != 2) {
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
                 fb[j][0] = *reinterpret_cast<const float4*>(Bs + buf * BN * CLD + fb_off[j][0]);
                 fb[j][1] = *reinterpret_cast<const float4*>(Bs + buf * BN * CLD + fb_off[j][1]);
+            }
             }
         }
         if (!ABL || !(p.ablate & (1 | 256))) {
@@ -684,7 +711,41 @@ conv_mfma_kernel(const ConvParams p) {
             tap_offsets();
         }
         if (ABL && (p.ablate & 64)) __builtin_amdgcn_s_setprio(1);
-        if constexpr (X3) {
+        if constexpr (X3 == 2) {
+            // weights pre-split (three bf16 planes in LDS, one 16-byte read per plane and column tile: lane (lr, lh) takes k = 8 lh .. 8 lh + 7
+            // of row wn * WN + j * 32 + lr); the activations are split here as in the X3 == 1 form -- 2 instead of 2 + TN split blocks per chunk.
+            // The planes were made with split_bf16x3 itself (bf16x3_split_weights below): same values, same six products in the same order as the
+            // in-loop form => bit-identical to it.
+            u32x4 Ah[TM], Am[TM], Al[TM];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) split_bf16x3(fa[i][0], fa[i][1], Ah[i], Am[i], Al[i]);
+            auto mm16 = [](const u32x4& a, const u32x4& b, f32x16 c) {
+                return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+            };
+            const char* bs3 = reinterpret_cast<const char*>(Bs) + (buf * 3 * BN) * 32 + lh * 16;
+#pragma unroll
+            for (int j0 = 0; j0 < TN; j0 += 2) {
+                constexpr int JN = TN < 2 ? TN : 2;
+                u32x4 Bh[JN], Bm[JN], Bl[JN];
+#pragma unroll
+                for (int jj = 0; jj < JN; ++jj) {
+                    const int r = wn * WN + (j0 + jj) * 32 + lr;
+                    Bh[jj] = *reinterpret_cast<const u32x4*>(bs3 + (0 * BN + r) * 32);
+                    Bm[jj] = *reinterpret_cast<const u32x4*>(bs3 + (1 * BN + r) * 32);
+                    Bl[jj] = *reinterpret_cast<const u32x4*>(bs3 + (2 * BN + r) * 32);
+                }
+#pragma unroll
+                for (int t = 0; t < 6; ++t)
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int jj = 0; jj < JN; ++jj) {
+                            const u32x4& a = t == 0 ? Al[i] : t == 1 ? Ah[i] : t == 2 ? Am[i] : t == 3 ? Am[i] : Ah[i];
+                            const u32x4& b = t == 0 ? Bh[jj] : t == 1 ? Bl[jj] : t == 2 ? Bm[jj] : t == 3 ? Bh[jj] : t == 4 ? Bm[jj] : Bh[jj];
+                            acc[i][j0 + jj] = mm16(a, b, acc[i][j0 + jj]);
+                        }
+            }
+        } else if constexpr (X3 == 1) {
             // a lane's two float4 are k = 8 lh .. 8 lh + 7 of its row: exactly the 8 bf16 the 32x32x16 MFMA takes from it
             u32x4 Ah[TM], Am[TM], Al[TM];
 #pragma unroll
@@ -864,6 +925,25 @@ conv_mfma_kernel(const ConvParams p) {
     }
 }
 
+// (round 6) weights of a bf16x3 layer split ONCE, with the loop's own split function: out = three bf16 planes [3][n] (h, m, l), n even
+__global__ void __launch_bounds__(256) bf16x3_split_kernel(const float* __restrict__ w, unsigned short* __restrict__ o, int64_t n) {
+    const int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 8;
+    if (i >= n) return;       // (n is a multiple of 16: whole groups of eight)
+    const float4 q0 = *reinterpret_cast<const float4*>(w + i), q1 = *reinterpret_cast<const float4*>(w + i + 4);
+    u32x4 H, M, L;
+    split_bf16x3(q0, q1, H, M, L);
+    *reinterpret_cast<u32x4*>(o + i) = H;
+    *reinterpret_cast<u32x4*>(o + n + i) = M;
+    *reinterpret_cast<u32x4*>(o + 2 * n + i) = L;
+}
+
+int bf16x3_split_weights(const float* w, unsigned short* out, int64_t n, hipStream_t stream) {
+    if (n <= 0 || n % 16) return MM_ERR_INVALID_ARG;
+    hipLaunchKernelGGL(bf16x3_split_kernel, dim3((unsigned)((n / 8 + 255) / 256)), dim3(256), 0, stream, w, out, n);
+    MM_LAUNCH_CHECK();
+    return MM_OK;
+}
+
 // Per-device caches (relaxed atomics: a race only repeats the query, every thread stores the same value).
 constexpr int kMaxDev = 64;
 static int cur_dev_slot() {
@@ -901,7 +981,7 @@ static int num_cus() {
     return v;
 }
 
-template <int BM, int BN, int WGM, int WGN, int KMODE, bool ABL = false, bool X3 = false>
+template <int BM, int BN, int WGM, int WGN, int KMODE, bool ABL = false, int X3 = 0>
 static int launch_km(ConvParams p, hipStream_t stream) {
     fastdiv_make(p.Ho * p.Wo, p.div_hw_mul, p.div_hw_sh);
     fastdiv_make(p.Wo, p.div_wo_mul, p.div_wo_sh);
@@ -913,7 +993,7 @@ static int launch_km(ConvParams p, hipStream_t stream) {
     if (blocks <= 0 || blocks > 0x7fffffff) return MM_ERR_INVALID_ARG;
     if (prof_enabled()) {
         char tag[64];
-        snprintf(tag, sizeof(tag), "M=%d K=%d N=%d k%d s%d t%dx%d b%d%s", p.M - p.m_off, p.K, p.Cout, p.kh, p.stride, BM, BN, p.batch, X3 ? " x3" : "");
+        snprintf(tag, sizeof(tag), "M=%d K=%d N=%d k%d s%d t%dx%d b%d%s", p.M - p.m_off, p.K, p.Cout, p.kh, p.stride, BM, BN, p.batch, X3 == 2 ? " x3p x3" : X3 ? " x3" : "");
         prof_before(0, 2.0 * (double)(p.M - p.m_off) * (double)(p.kh * p.kw * p.Cin_real) * (double)p.Cout * (double)p.batch, stream, tag);
     }
     hipLaunchKernelGGL((conv_mfma_kernel<BM, BN, WGM, WGN, KMODE, ABL, X3>), dim3((unsigned)blocks), dim3(WGM * WGN * 64), 0, stream, p);
@@ -932,8 +1012,8 @@ static int launch_cfg(const ConvParams& p, hipStream_t stream) {
         return launch_km<BM, BN, WGM, WGN, 5>(p, stream);
     }
     if constexpr (BN >= 64 && BM != 256) {      // the bf16x3 instantiations exist for the 1x1 forms on the 64x64 / 128x128 tiles (and 128x256 below)
-        if (p.x3 && p.in2) return launch_km<BM, BN, WGM, WGN, 6, false, true>(p, stream);
-        if (p.x3 && p.kh == 1 && p.kw == 1 && p.pad == 0) return launch_km<BM, BN, WGM, WGN, 3, false, true>(p, stream);
+        if (p.x3 && p.in2) return launch_km<BM, BN, WGM, WGN, 6, false, 1>(p, stream);
+        if (p.x3 && p.kh == 1 && p.kw == 1 && p.pad == 0) return launch_km<BM, BN, WGM, WGN, 3, false, 1>(p, stream);
     }
     if (p.sched1x1 && p.in2) return launch_km<BM, BN, WGM, WGN, 8>(p, stream);
     if (p.sched1x1) return launch_km<BM, BN, WGM, WGN, 7>(p, stream);
@@ -1090,10 +1170,15 @@ int conv_forward(const ConvParams& p0, hipStream_t stream) {
 #ifndef MM_X3_WIDE
 #define MM_X3_WIDE 1   // 1: the bf16x3 form of the 128x256 tile runs on FOUR waves with 64x128 wave tiles (fewer split instructions per MFMA); 0: eight waves, 64x64
 #endif
+            // (round 6, opt-in MM_X3_PRESPLIT=1) weights pre-split into three bf16 planes (ConvParams::w3): eight waves, the B fragments need no split
+            // in the loop.  Measured SLOWER than the four-wave form below that splits both operands in the loop (154-181 vs 183-206 TFLOP/s per layer,
+            // profiles/r06_ab_x3_presplit.txt): 96 B per B row and ring slot make the ring 96 KB -- one workgroup per CU -- and the 64x64 wave tiles
+            // amortise the remaining A split over two column tiles instead of four
+            if (p.x3 && p.w3) return p.in2 ? launch_km<128, 256, 2, 4, 6, false, 2>(p, stream) : launch_km<128, 256, 2, 4, 3, false, 2>(p, stream);
 #if MM_X3_WIDE
-            if (p.x3) return p.in2 ? launch_km<128, 256, 2, 2, 6, false, true>(p, stream) : launch_km<128, 256, 2, 2, 3, false, true>(p, stream);
+            if (p.x3) return p.in2 ? launch_km<128, 256, 2, 2, 6, false, 1>(p, stream) : launch_km<128, 256, 2, 2, 3, false, 1>(p, stream);
 #else
-            if (p.x3) return p.in2 ? launch_km<128, 256, 2, 4, 6, false, true>(p, stream) : launch_km<128, 256, 2, 4, 3, false, true>(p, stream);
+            if (p.x3) return p.in2 ? launch_km<128, 256, 2, 4, 6, false, 1>(p, stream) : launch_km<128, 256, 2, 4, 3, false, 1>(p, stream);
 #endif
             if (p.sched1x1) return p.in2 ? launch_km<128, 256, 2, 4, 8>(p, stream) : launch_km<128, 256, 2, 4, 7>(p, stream);
             if (p.in2) return launch_km<128, 256, 2, 4, 6>(p, stream);

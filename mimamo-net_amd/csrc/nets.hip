@@ -23,6 +23,9 @@ struct Layer {
     int cin = 0, cin_p = 0, cout = 0, k = 1, stride = 1, pad = 0, K = 0, Kpad = 0, relu = 0, korder = 0;
     int wino_cin = 0;          // channels of the Winograd-domain weights: cin, or cin padded with zero columns (wino_pad)
     int tile = 0;              // conv engine tile for this layer (0 = automatic; measurement knob MM_STEM_TILE for the stem)
+    // (round 6) bf16x3 mode: `w` / `wino_u4` pre-split into three bf16 planes (made by mm_resnet50_set_precision(h, 1) for the layers the
+    // mode touches whose tile is 128x256); null = the loop splits the weight fragments itself
+    unsigned short *w3 = nullptr, *wino_u4_3 = nullptr;
 };
 
 struct DeviceArena {
@@ -194,6 +197,7 @@ static int run_layer(const Layer& L, const float* in, int B, int H, int W, int i
     p.kh = L.k; p.kw = L.k; p.stride = L.stride; p.pad = L.pad;
     p.K = L.K; p.Kpad = L.Kpad; p.relu = L.relu; p.Cin_real = L.cin; p.korder = L.korder; p.force_tile = L.tile;
     p.x3 = x3 && L.k == 1 && L.Kpad >= kX3MinK;
+    p.w3 = p.x3 ? L.w3 : nullptr; p.w3_plane = (int64_t)L.cout * L.Kpad;
     p.no_sched = no_sched;
     p.hpool = hpool;
     p.use_panel = use_panel;
@@ -215,6 +219,7 @@ static int run_layer_dual(const Layer& L, const float* in, int B, int H, int W, 
     p.K = L.K; p.Kpad = L.Kpad; p.relu = 1; p.Cin_real = L.K;
     p.in2 = in2; p.H2 = H2; p.W2 = W2; p.C2 = C2; p.in2_cstride = C2; p.stride2 = stride2;
     p.x3 = x3 && L.Kpad >= kX3MinK;
+    p.w3 = p.x3 ? L.w3 : nullptr; p.w3_plane = (int64_t)L.cout * L.Kpad;
     p.no_sched = no_sched;
     return conv_forward(p, s);
 }
@@ -270,6 +275,7 @@ static int run_layer_wino(const Layer& L, const float* in, int B, int H, int W, 
     p.Cout = L.cout; p.out_cstride = L.cout; p.kh = 1; p.kw = 1; p.stride = 1; p.K = wc; p.Kpad = wc; p.Cin_real = wc;
     p.batch = npos; p.in_bstride = ntile * wc; p.w_bstride = (int64_t)L.cout * wc; p.out_bstride = ntile * L.cout;
     p.x3 = x3 && wc >= kX3MinK;      // the position GEMMs of the three-kernel form (conv5_x: K = 512)
+    p.w3 = (p.x3 && m == 4) ? L.wino_u4_3 : nullptr; p.w3_plane = (int64_t)npos * L.cout * wc;
     p.no_sched = no_sched;
     rc = conv_forward(p, s);
     if (rc != MM_OK) return rc;
@@ -542,8 +548,46 @@ int mm_resnet50_set_winograd(mm_resnet50_t* h, int enable) {
     return MM_OK;
 }
 
+// bf16x3 with MM_X3_PRESPLIT=1 (round 6, verdict item 7 -- OPT-IN: built, bit-identical, measured SLOWER, profiles/r06_ab_x3_presplit.txt): the
+// weights of the layers the mode touches, split once into three bf16 planes; the 128x256 tile then needs no split of its B fragments in the
+// loop.  Default: every split in the loop (round-5 form).
+static int ensure_x3_weights(mm_resnet50_t* h) {
+    using namespace mm;
+    const char* e = getenv("MM_X3_PRESPLIT");
+    if (!e || atoi(e) != 1) return MM_OK;
+    auto split = [&](const float* w, int64_t n, unsigned short** out) -> int {
+        if (*out || !w || n <= 0 || n % 16) return MM_OK;
+        void* d = nullptr;
+        MM_HIP(hipMalloc(&d, (size_t)n * 3 * sizeof(unsigned short)));
+        h->arena.ptrs.push_back(d);
+        const int rc = bf16x3_split_weights(w, (unsigned short*)d, n, nullptr);
+        if (rc != MM_OK) return rc;
+        *out = (unsigned short*)d;
+        return MM_OK;
+    };
+    for (auto& Bk : h->blocks) {
+        for (Layer* L : {&Bk.proj, &Bk.reduce, &Bk.increase, &Bk.inc_proj})
+            if (L->w && L->k == 1 && L->Kpad >= kX3MinK && L->cout % 256 == 0) {
+                const int rc = split(L->w, (int64_t)L->cout * L->Kpad, &L->w3);
+                if (rc != MM_OK) return rc;
+            }
+        Layer& C = Bk.conv3;
+        if (C.wino_u4 && C.wino_cin >= kX3MinK && C.cout % 256 == 0) {
+            const int rc = split(C.wino_u4, (int64_t)36 * C.cout * C.wino_cin, &C.wino_u4_3);
+            if (rc != MM_OK) return rc;
+        }
+    }
+    MM_HIP(hipDeviceSynchronize());
+    return MM_OK;
+}
+
 int mm_resnet50_set_precision(mm_resnet50_t* h, int mode) {
     if (!h || (mode != 0 && mode != 1)) return MM_ERR_INVALID_ARG;
+    if (mode == 1) {
+        MM_CHECK_DEVICE(h);
+        const int rc = ensure_x3_weights(h);
+        if (rc != MM_OK) return rc;
+    }
     h->precision = mode;
     return MM_OK;
 }

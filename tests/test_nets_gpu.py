@@ -837,6 +837,36 @@ def test_head_scheduled_conv_loops_are_bit_identical_to_the_base_modes(head, dev
     monkeypatch.delenv("MM_CONV_SCHED")
 
 
+def test_bf16x3_presplit_weights_are_bit_identical_to_the_in_loop_split(dev, monkeypatch):
+    """Round 6 (verdict item 7, `extra` only; OPT-IN with MM_X3_PRESPLIT=1 -- built, bit-identical, measured slower,
+    profiles/r06_ab_x3_presplit.txt): mm_resnet50_set_precision(h, 1) splits the weights of the layers the mode touches ONCE into three bf16
+    planes (with the loop's own split function) and the 128x256 tile reads its B fragments ready-made -- the activations are still split
+    in the loop.  Same h / m / l values, same six products in the same order: the same BITS as the default form that splits both operands
+    in the loop, at a batch large enough for the 128x256 tile (conv4_x / conv5_x layers, the batched conv5_x position GEMMs) and at a small
+    one (everything on the in-loop tiles either way)."""
+    from mimamo_net_amd.resnet50_extractor import Resnet50_Extractor
+    sd = weights.make_resnet50_state_dict(seed=0)
+    for n in (3, 352):
+        xt = torch.from_numpy(_images(min(n, 4), 47)).to(dev).repeat((n + 3) // 4, 1, 1, 1)[:n].contiguous()
+        twin = Resnet50_Extractor(state_dict=sd, device=dev)
+        twin.set_precision("bf16x3")
+        monkeypatch.setenv("MM_X3_PRESPLIT", "1")
+        new = Resnet50_Extractor(state_dict=sd, device=dev)
+        new.set_precision("bf16x3")
+        monkeypatch.delenv("MM_X3_PRESPLIT")
+        tags = _last_conv_tags(lambda: new.get_vec(xt))
+        if n >= 352:
+            assert sum(" x3p " in t for t in tags) >= 6, tags
+            assert not any(" x3p " in t for t in _last_conv_tags(lambda: twin.get_vec(xt)))
+        a, b = new.get_vec(xt), twin.get_vec(xt)
+        assert torch.isfinite(a).all() and torch.equal(a, b), (n, (a - b).abs().max().item())
+        new.set_precision("fp32")
+        twin.set_precision("fp32")
+        assert torch.equal(new.get_vec(xt), twin.get_vec(xt))
+        new.close()
+        twin.close()
+
+
 def test_resnet50_bf16x3_mode(resnet, oracle, dev):
     """mm_resnet50_set_precision(1) -- bench.py's extra.bf16x3, never the headline: the 1x1 layers with K >= 512 as six bf16 MFMA
     products of three-way split fp32 operands.  pool5 against the fp32 oracle and against a float64 evaluation at the CONTRACT bounds
