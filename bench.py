@@ -830,7 +830,7 @@ def run_rank(args):
     live_note = None
     if live_traffic and live_traffic.get("conv"):
         live_note = ("HBM bytes per step over all conv launches, rocprofv3 PMC (2*FETCH_SIZE + WRITE_SIZE)*1024, measured LIVE by this run "
-                     "(two child runs of bench.py under rocprofv3, %.0f s); committed summary for the same sources: %s"
+                     "(child runs of bench.py under rocprofv3: FETCH_SIZE, WRITE_SIZE and an SQ / GRBM pass, %.0f s in all); committed summary for the same sources: %s"
                      % (live_traffic["seconds"], ("%.4g bytes (profiles/%s)" % (traffic, traffic_file)) if traffic else "none"))
         traffic, traffic_file = live_traffic["conv"], "live"
         if live_traffic.get("phase"):
