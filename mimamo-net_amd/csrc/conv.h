@@ -40,7 +40,8 @@ struct ConvParams {
     int H2, W2, C2, in2_cstride, in2_coff, stride2;
     int sched1x1;    // set by conv_forward: 1x1 layer with K % 16 == 0 on the scheduled loop (conv_mfma.hip KMODE 7 / 8)
     int no_sched;    // 1: keep modes 3 / 6 for such a layer (the parity twin of the scheduled loop)
-    int use_panel;   // 1: a layer conv_panel.hip applies to runs there (MM_CONV_PANEL=1: opt-in, measured slower than the engine -- the tested twin)
+    int use_panel;   // 1 / 2: a layer conv_panel.hip applies to runs there on 128-row / 64-row panels (MM_CONV_PANEL=1 | 2: opt-in, measured slower than
+                     // the engine -- the tested twins)
     int x3;          // 1: 1x1 layer on the bf16 matrix pipes through a three-way bf16 split of both fp32 operands (conv_mfma.hip X3; `extra` only)
     const unsigned short* w3;   // (round 6, x3 only) the same weights pre-split into three bf16 planes [3][w3_plane] (bf16x3_split_weights): the 128x256
     int64_t w3_plane;           // tile then reads the B fragments ready-made (no split of the weights in the loop); null = split in the loop.  Elements
@@ -62,6 +63,8 @@ int bf16x3_split_weights(const float* w, unsigned short* out, int64_t n, hipStre
 // only with ConvParams::use_panel (measured slower: profiles/r06_ab_conv_panel.txt); bit-identical to the engine.
 bool conv_panel_supported(const ConvParams& p);
 int conv_panel_forward(const ConvParams& p, hipStream_t stream);
+int conv_panel_rows(const ConvParams& p);      // 128 (use_panel == 1) or 64 (use_panel == 2: two workgroups per CU)
+int conv_panel_per_cu(const ConvParams& p);
 
 // NCHW [N,C,HW] -> NHWC [N,HW,cstride] at channel offset coff; channels [C, cpad) are zero-filled
 int nchw_to_nhwc(const float* in, float* out, int64_t N, int C, int HW, int cstride, int coff, int cpad, hipStream_t s);

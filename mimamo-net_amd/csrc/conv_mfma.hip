@@ -1085,16 +1085,17 @@ int conv_forward(const ConvParams& p0, hipStream_t stream) {
     // built, bit-identical, measured SLOWER than the engine (profiles/r06_ab_conv_panel.txt).  One workgroup per CU, so a launch is whole
     // rounds of num_cus() panels; the rows of a thin last round go to the engine below instead (same sums in the same order either way).
     if (p.use_panel && p.force_tile == 0 && p.m_off == 0 && p.m_end == 0 && conv_panel_supported(p)) {
-        const int64_t slots = num_cus();
-        const int64_t tm = (p.M + 127) / 128;
+        const int pbm = conv_panel_rows(p);
+        const int64_t slots = (int64_t)num_cus() * conv_panel_per_cu(p);
+        const int64_t tm = (p.M + pbm - 1) / pbm;
         const int64_t full = tm / slots, rest = tm - full * slots;
         if (full >= 1) {
             if (rest == 0 || rest * 2 >= slots) return conv_panel_forward(p, stream);
             ConvParams pb = p, pr = p;
-            pb.M = (int)(full * slots * 128);
+            pb.M = (int)(full * slots * pbm);
             pr.m_off = pb.M;
             pr.use_panel = 0;
-            const int64_t t128 = rest * ((p.Cout + 127) / 128);
+            const int64_t t128 = ((p.M - pb.M + 127) / 128) * ((p.Cout + 127) / 128);
             pr.force_tile = t128 * 2 >= (int64_t)num_cus() * 3 ? 1 : 3;
             const int rc = conv_panel_forward(pb, stream);
             return rc != MM_OK ? rc : conv_forward(pr, stream);

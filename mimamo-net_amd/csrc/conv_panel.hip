@@ -36,18 +36,20 @@ namespace mm {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
 
-constexpr int PBM = 128;          // rows of a panel
 constexpr int PCH = 16;           // floats per chunk (the engine's CBK / CLD)
-constexpr int PNW = 8;            // waves: 2 (m) x 4 (n), wave tile 64 x 64 of a 128 x 256 N-step
+// PBM rows per panel, PNW = PBM / 16 waves: 128 rows -> 2 (m) x 4 (n) waves, one 128 KB workgroup per CU; 64 rows -> 1 x 4 waves, 64 KB: TWO
+// workgroups per CU at independent phases (the second form, use_panel == 2: built after the first one's ablations pointed at its lock-step
+// rounds and exposed epilogues).  Wave tile 64 x 64 of a PBM x 256 N-step either way.
 constexpr int PRING = 4;          // chunks of B fragments in flight per wave
 #ifndef MM_PANEL_ABL
 #define MM_PANEL_ABL 0            // variant builds only (tools/_ab): 1 = no residual loads / one store per tile (results wrong), 2 = no weight loads in the
 #endif                            // loop (results wrong), 4 = the wm = 0 waves at a higher issue priority, 8 = non-temporal instead of plain stores
 
-template <int NKC>                // chunks of the panel: K = 16 NKC (NKC <= 16)
-__global__ void __launch_bounds__(PNW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
+template <int NKC, int PBM>       // chunks of the panel: K = 16 NKC (NKC <= 16); rows of the panel
+__global__ void __launch_bounds__(PBM / 16 * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
 conv_panel_kernel(const ConvParams p) {
-    extern __shared__ __attribute__((aligned(16))) float As[];       // [NKC][128][16], slot s of row m holds k-quad s ^ ((m >> 2) & 3)
+    constexpr int PNW = PBM / 16;
+    extern __shared__ __attribute__((aligned(16))) float As[];       // [NKC][PBM][16], slot s of row m holds k-quad s ^ ((m >> 2) & 3)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 2, wn = wave & 3;
     const int lr = lane & 31, lh = lane >> 5;
@@ -207,28 +209,37 @@ bool conv_panel_supported(const ConvParams& p) {
     return p.kh == 1 && p.kw == 1 && p.pad == 0 && p.stride == 1 && p.korder == 0 && !p.in2 && !p.x3 && !p.post_scale && !p.hpool && p.batch <= 1 &&
            p.H == p.Ho && p.W == p.Wo && p.K == p.Kpad && (p.K == 256 || p.K == 128) && p.Cin == p.K && p.in_cstride >= p.K && p.Cout % 256 == 0 &&
            p.Cout >= 512 && ((p.in_cstride | p.in_coff | p.out_cstride | p.out_coff | p.res_cstride | p.res_coff) & 3) == 0 &&
-           (int64_t)PBM * p.in_cstride * 4 < 0x7FFFF000ll;
+           (int64_t)128 * p.in_cstride * 4 < 0x7FFFF000ll;
 }
+
+template <int NKC, int PBM>
+static int launch_panel(const ConvParams& p, int tiles, hipStream_t stream) {
+    const int lds = NKC * PBM * PCH * 4;
+    MM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_panel_kernel<NKC, PBM>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    hipLaunchKernelGGL((conv_panel_kernel<NKC, PBM>), dim3((unsigned)tiles), dim3(PBM / 16 * 64), lds, stream, p);
+    return MM_OK;
+}
+
+// rows of one panel / panels resident per CU for the form ConvParams::use_panel selects
+int conv_panel_rows(const ConvParams& p) { return p.use_panel == 2 ? 64 : 128; }
+int conv_panel_per_cu(const ConvParams& p) { return p.use_panel == 2 ? 2 : 1; }
 
 // rows [p.m_off, p.M) -- conv_forward has set M (and m_off / m_end for a tail split)
 int conv_panel_forward(const ConvParams& p, hipStream_t stream) {
-    const int tiles = (p.M - p.m_off + PBM - 1) / PBM;
+    const int pbm = conv_panel_rows(p);
+    const int tiles = (p.M - p.m_off + pbm - 1) / pbm;
     if (tiles <= 0) return MM_OK;
     const int nkc = p.K / PCH;
-    const int lds = nkc * PBM * PCH * 4;
     if (prof_enabled()) {
         char tag[64];
-        snprintf(tag, sizeof(tag), "M=%d K=%d N=%d k1 s1 t128xNp b1", p.M - p.m_off, p.K, p.Cout);
+        snprintf(tag, sizeof(tag), "M=%d K=%d N=%d k1 s1 t%dxNp b1", p.M - p.m_off, p.K, p.Cout, pbm);
         prof_before(0, 2.0 * (double)(p.M - p.m_off) * (double)p.K * (double)p.Cout, stream, tag);
     }
-    if (nkc == 16) {
-        MM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_panel_kernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        hipLaunchKernelGGL((conv_panel_kernel<16>), dim3((unsigned)tiles), dim3(PNW * 64), lds, stream, p);
-    } else {
-        MM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_panel_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        hipLaunchKernelGGL((conv_panel_kernel<8>), dim3((unsigned)tiles), dim3(PNW * 64), lds, stream, p);
-    }
+    int rc;
+    if (pbm == 128) rc = nkc == 16 ? launch_panel<16, 128>(p, tiles, stream) : launch_panel<8, 128>(p, tiles, stream);
+    else rc = nkc == 16 ? launch_panel<16, 64>(p, tiles, stream) : launch_panel<8, 64>(p, tiles, stream);
     prof_after(0, stream);
+    if (rc != MM_OK) return rc;
     MM_LAUNCH_CHECK();
     return MM_OK;
 }

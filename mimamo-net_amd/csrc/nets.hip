@@ -427,7 +427,7 @@ int mm_conv2d_nhwc(const float* in, const float* w, const float* bias, const flo
     p.K = kh * kw * Cin; p.Kpad = (p.K + 15) / 16 * 16; p.relu = relu; p.force_tile = tile; p.korder = korder;
     {
         const char* cp = getenv("MM_CONV_PANEL");      // read per call (a test switches it): opt-in panel kernel for the shapes it takes
-        p.use_panel = cp && atoi(cp) == 1;
+        p.use_panel = cp ? (atoi(cp) == 1 ? 1 : atoi(cp) == 2 ? 2 : 0) : 0;
     }
     return conv_forward(p, (hipStream_t)stream);
 }
@@ -456,7 +456,7 @@ int mm_resnet50_create(mm_resnet50_t** out, const float* blob, int64_t n_floats,
         const char* cs = getenv("MM_CONV_SCHED");  // measurement knob / parity twin: 0 = no scheduled 1x1 loop in the conv engine
         h->no_sched = cs ? atoi(cs) == 0 : 0;
         const char* cp = getenv("MM_CONV_PANEL");  // measurement knob / parity twin: 1 = the LDS-resident-panel kernel for the K = 256 increase layers
-        h->use_panel = cp ? atoi(cp) == 1 : 0;
+        h->use_panel = cp ? (atoi(cp) == 1 ? 1 : atoi(cp) == 2 ? 2 : 0) : 0;
         const char* fp = getenv("MM_FUSE_PROJ");   // measurement knob: 0 = projection shortcut as its own launch + residual read
         h->fuse_proj = fp ? atoi(fp) : 1;
         const char* fpl = getenv("MM_FUSE_POOL");  // measurement knob: 0 = max-pool and conv2_1's reduce conv as two launches (the parity twin),

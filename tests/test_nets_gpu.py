@@ -229,14 +229,15 @@ PANEL_CASES = [
 ]
 
 
+@pytest.mark.parametrize("form", [1, 2])
 @pytest.mark.parametrize("case", PANEL_CASES)
-def test_conv_panel_kernel_is_bit_identical_to_the_engine(pkg, dev, case, monkeypatch):
-    """Round 6 (csrc/conv_panel.hip; OPT-IN with MM_CONV_PANEL=1 -- built, bit-identical, measured slower than the engine,
-    profiles/r06_ab_conv_panel.txt): 1x1 layers with K = 256 / 128 and N >= 512 keep their 128-row activation panel in LDS for ALL N,
-    stream the weights through registers (no workgroup barrier in the main loop) and write 16-byte channel quads straight from the
-    TRANSPOSED accumulators.  Same products in the same order per output element as the engine's 128x256 tile (tile = 5 forces it):
-    the same BITS, residual / bias / ReLU included; whole rounds of panels go to the panel kernel, the rows of a thin last round to
-    the engine (launch counts checked); sampled rows against float64."""
+def test_conv_panel_kernel_is_bit_identical_to_the_engine(pkg, dev, case, form, monkeypatch):
+    """Round 6 (csrc/conv_panel.hip; OPT-IN with MM_CONV_PANEL=1 | 2 -- built, bit-identical, measured slower than the engine,
+    profiles/r06_ab_conv_panel.txt): 1x1 layers with K = 256 / 128 and N >= 512 keep their activation panel (form 1: 128 rows, one
+    workgroup per CU; form 2: 64 rows, two per CU) in LDS for ALL N, stream the weights through registers (no workgroup barrier in the
+    main loop) and write 16-byte channel quads straight from the TRANSPOSED accumulators.  Same products in the same order per output
+    element as the engine's 128x256 tile (tile = 5 forces it): the same BITS, residual / bias / ReLU included; whole rounds of panels go
+    to the panel kernel, the rows of a thin last round to the engine (launch counts checked); sampled rows against float64."""
     from mimamo_net_amd import _lib
     B, side, Ci, Co, with_res, relu = case
     M = B * side * side
@@ -254,20 +255,23 @@ def test_conv_panel_kernel_is_bit_identical_to_the_engine(pkg, dev, case, monkey
         return out
 
     outs = {}
-    assert not any(t.endswith("t128xNp b1") for t in _last_conv_tags(lambda: run(0)))       # the default stays in the engine
-    monkeypatch.setenv("MM_CONV_PANEL", "1")
+    pbm, per_cu = (128, 1) if form == 1 else (64, 2)
+    tag = "t%dxNp b1" % pbm
+    assert not any(t.endswith("xNp b1") for t in _last_conv_tags(lambda: run(0)))       # the default stays in the engine
+    monkeypatch.setenv("MM_CONV_PANEL", str(form))
     n_auto = _count_conv_launches(lambda: outs.__setitem__(0, run(0)))
     tags = _last_conv_tags(lambda: run(0))
-    assert any(t.endswith("t128xNp b1") for t in tags), tags
+    assert any(t.endswith(tag) for t in tags), tags
     outs[5] = run(5)
-    tm = (M + 127) // 128
-    rest = tm % 256
-    assert n_auto == (1 if rest == 0 or rest * 2 >= 256 else 2), (n_auto, tm, rest, tags)
+    tm = (M + pbm - 1) // pbm
+    slots = 256 * per_cu
+    rest = tm % slots
+    assert n_auto == (1 if rest == 0 or rest * 2 >= slots else 2), (n_auto, tm, rest, tags)
     assert torch.isfinite(outs[0]).all()
     assert torch.equal(outs[0], outs[5]), ((outs[0] - outs[5]).abs().max().item(), (outs[0] != outs[5]).float().mean().item())
     for _ in range(3):
-        assert torch.equal(run(0), outs[0])                      # and run to run (eight free-running waves, no barrier in the loop)
-    bnd = (tm // 256) * 256 * 128
+        assert torch.equal(run(0), outs[0])                      # and run to run (free-running waves, no barrier in the loop)
+    bnd = (tm // slots) * slots * pbm
     rows = sorted(set(r for r in [0, 1, 31, 32, 63, 64, 127, 128, bnd - 129, bnd - 1, bnd, bnd + 1, M - 129, M - 128, M - 2, M - 1] +
                       list(range(7, M, 2053)) if 0 <= r < M))
     idx = torch.tensor(rows, device=dev)
@@ -287,16 +291,18 @@ def test_resnet50_panel_kernel_twin(dev, monkeypatch):
     sd = weights.make_resnet50_state_dict(seed=0)
     xt = torch.from_numpy(_images(4, 43)).to(dev).repeat(44, 1, 1, 1).contiguous()
     twin = Resnet50_Extractor(state_dict=sd, device=dev)
-    monkeypatch.setenv("MM_CONV_PANEL", "1")
-    new = Resnet50_Extractor(state_dict=sd, device=dev)
-    monkeypatch.delenv("MM_CONV_PANEL")
-    tags = _last_conv_tags(lambda: new.get_vec(xt))
-    assert sum(t.endswith("t128xNp b1") for t in tags) == 5, tags
-    assert not any(t.endswith("t128xNp b1") for t in _last_conv_tags(lambda: twin.get_vec(xt)))
-    a, b = new.get_vec(xt), twin.get_vec(xt)
-    assert torch.isfinite(a).all() and torch.equal(a, b), (a - b).abs().max().item()
-    assert torch.equal(a[:4], a[172:176])                           # the four distinct images repeat
-    new.close()
+    b = twin.get_vec(xt)
+    assert not any(t.endswith("xNp b1") for t in _last_conv_tags(lambda: twin.get_vec(xt)))
+    for form, tag in ((1, "t128xNp b1"), (2, "t64xNp b1")):
+        monkeypatch.setenv("MM_CONV_PANEL", str(form))
+        new = Resnet50_Extractor(state_dict=sd, device=dev)
+        monkeypatch.delenv("MM_CONV_PANEL")
+        tags = _last_conv_tags(lambda: new.get_vec(xt))
+        assert sum(t.endswith(tag) for t in tags) == 5, tags
+        a = new.get_vec(xt)
+        assert torch.isfinite(a).all() and torch.equal(a, b), (form, (a - b).abs().max().item())
+        assert torch.equal(a[:4], a[172:176])                           # the four distinct images repeat
+        new.close()
     twin.close()
 
 
