@@ -46,6 +46,36 @@ __device__ __forceinline__ void row_pass(const float* in, int y, int x0, float (
     }
 }
 
+// The same pass with the five 16-byte chunk offsets (floats, relative to the plane) made ONCE per thread by row_chunk_offsets: a chunk outside
+// the row points at the plane's slack [W * W, W * W + 16), which the caller keeps ZERO -- no select on the address or on the data in the frame
+// loop (round 6: 20 v_cndmask per frame and thread in the window kernels, and vector instructions are what those kernels are bound by).  Same
+// values into the same fused multiply-adds in the same order as row_pass: bit-identical.
+template <int W>
+__device__ __forceinline__ void row_chunk_offsets(int y, int x0, int (&off)[(PX + 2 * PADX) / 4]) {
+#pragma unroll
+    for (int q = 0; q < (PX + 2 * PADX) / 4; ++q) {
+        const int xs = x0 - PADX + 4 * q;
+        off[q] = (xs >= 0 && xs < W) ? y * W + xs : W * W + 4 * (q & 3);
+    }
+}
+template <int W>
+__device__ __forceinline__ void row_pass_pre(const float* in, const int (&off)[(PX + 2 * PADX) / 4], float (&h)[PX]) {
+    float v[PX + 2 * PADX];
+#pragma unroll
+    for (int q = 0; q < (PX + 2 * PADX) / 4; ++q) {
+        // (every offset is a multiple of four floats and the planes are 16-byte aligned: say so, or hipcc splits the read into b32 / b64 pieces)
+        const float4 a = *reinterpret_cast<const float4*>(__builtin_assume_aligned(in + off[q], 16));
+        v[4 * q] = a.x; v[4 * q + 1] = a.y; v[4 * q + 2] = a.z; v[4 * q + 3] = a.w;
+    }
+#pragma unroll
+    for (int p = 0; p < PX; ++p) {
+        float s = 0.f;
+#pragma unroll
+        for (int t = 0; t < TAP; ++t) s = fmaf(c_g[t], v[PADX - R + p + t], s);
+        h[p] = s;
+    }
+}
+
 template <int W>
 __device__ __forceinline__ void col_pass(const float* tmp, int y, int x0, float (&s)[PX]) {
     s[0] = s[1] = s[2] = s[3] = 0.f;

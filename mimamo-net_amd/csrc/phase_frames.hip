@@ -33,6 +33,32 @@ namespace mm {
 
 using namespace blur;
 
+// Sum over the 64 lanes of a wave, result in LANE 63, on the VALU's DPP path (row_shr 1 / 2 / 4 / 8, then row_bcast:15 and row_bcast:31 -- the
+// wave64 reduction of the GFX9 family): six v_add_f32 with a DPP source instead of six ds_bpermute_b32 + s_waitcnt round trips through the
+// LDS pipe per plane (round 6: the window kernels are bound by VALU + LDS issue, and 78 of their 420 LDS instructions were these shuffles).
+#ifndef MM_PW_ROW_PRE
+#define MM_PW_ROW_PRE 0         // 1: row_pass_pre -- the five chunk offsets of a thread made once, out-of-row chunks pointing at a zeroed slack, no
+#endif                          // select left in the frame loop (260 fewer vector instructions per thread).  Measured SLOWER (0.550 vs 0.510 ms,
+                                // profiles/r06_ab_phase_window_micro.txt): the lanes that read the shared zero slot conflict with the row reads
+                                // of their neighbours; the selects are cheaper than that.  Bit-identical either way.
+#ifndef MM_PW_DPP_REDUCE
+#define MM_PW_DPP_REDUCE 1      // 0: the round-3 __shfl_down tree (result in lane 0), for the A/B
+#endif
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_add(float v) {
+    const int moved = __builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xf, false);
+    return v + __int_as_float(moved);
+}
+__device__ __forceinline__ float wave_sum_lane63(float v) {
+    v = dpp_add<0x111, 0xf>(v);      // row_shr:1
+    v = dpp_add<0x112, 0xf>(v);      // row_shr:2
+    v = dpp_add<0x114, 0xf>(v);      // row_shr:4
+    v = dpp_add<0x118, 0xf>(v);      // row_shr:8   -> lane 15 of every row holds its row's sum
+    v = dpp_add<0x142, 0xa>(v);      // row_bcast:15 into rows 1 and 3
+    v = dpp_add<0x143, 0xc>(v);      // row_bcast:31 into rows 2 and 3 -> lane 63 holds the wave's sum
+    return v;
+}
+
 // ---- per (window, band): 12 phase-difference planes from the frame planes.
 //   A  every frame's B and phase planes are requested up front (26 independent loads per thread, one latency instead of one
 //      per barrier round); the wrapped steps are counted bytewise in one register per frame (k <= 12 per pixel), the difference planes start
@@ -75,7 +101,22 @@ phase_window2_kernel(const float* __restrict__ fr, const int32_t* __restrict__ i
     const int y = active ? tid / C::STRIPS : 0;
     const int x0 = active ? (tid - y * C::STRIPS) * PX : 0;
     const int px = y * W + x0;
-    for (int i = tid; i < WORK; i += C::NTHREADS) lds[i] = 0.f;    // the zero rows above / below tmp_x
+    // the zero rows above / below each tmp_x plane (column-pass halo; everything else is written before it is read -- round 6: the whole 61 KB
+    // region used to be cleared, 27 ds_write_b32 per thread)
+#ifndef MM_PW_CLEAR_ALL
+#define MM_PW_CLEAR_ALL 0       // 1: clear the whole working region (round-3 form), for the A/B
+#endif
+    if (MM_PW_CLEAR_ALL) {
+        for (int i = tid; i < WORK; i += C::NTHREADS) lds[i] = 0.f;
+    } else {
+        for (int i = tid; i < F * 2 * R * W; i += C::NTHREADS) {
+            const int f = i / (2 * R * W), r = i - f * (2 * R * W);
+            tmp_x[f * C::TMP_PLANE + (r < R * W ? r : (W + R) * W + (r - R * W))] = 0.f;
+        }
+        if (tid < F * 2 * PADX) in_x[(tid / (2 * PADX)) * C::IN_PLANE + W * W + tid % (2 * PADX)] = 0.f;   // the slack row_pass_pre reads as zero padding
+    }
+    int roff[(PX + 2 * PADX) / 4];                  // this thread's five row-pass chunks: loop constants
+    row_chunk_offsets<W>(y, x0, roff);
     if (tid == 0) first_wrap = P;
     const float TWO_PI_F = 6.28318530717958647692f, PI_F = 3.14159265358979323846f;
     // ---- A
@@ -142,7 +183,11 @@ phase_window2_kernel(const float* __restrict__ fr, const int32_t* __restrict__ i
             for (int f = 0; f < F; ++f) {
                 if (base + f >= P) continue;
                 float h[PX];
+#if MM_PW_ROW_PRE
+                row_pass_pre<W>(in_x + f * C::IN_PLANE, roff, h);
+#else
                 row_pass<W>(in_x + f * C::IN_PLANE, y, x0, h);
+#endif
                 *reinterpret_cast<float4*>(tmp_x + f * C::TMP_PLANE + (y + R) * W + x0) = float4{h[0], h[1], h[2], h[3]};
             }
         }
@@ -169,9 +214,14 @@ phase_window2_kernel(const float* __restrict__ fr, const int32_t* __restrict__ i
 #pragma unroll
     for (int k = 0; k < P - 1; ++k) {
         float v = active ? (d[k][0] + d[k][1]) + (d[k][2] + d[k][3]) : 0.f;
+#if MM_PW_DPP_REDUCE
+        v = wave_sum_lane63(v);
+        if (lane == 63) red[wave * (P - 1) + k] = v;
+#else
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
         if (lane == 0) red[wave * (P - 1) + k] = v;
+#endif
     }
     __syncthreads();                      // also: every blur read of the planes is done, they become the store staging
     constexpr int NWAVES = C::NTHREADS / 64;
@@ -267,7 +317,22 @@ __device__ __forceinline__ void phase_window2s_body(const float* __restrict__ fr
     const int y = active ? tid / C::STRIPS : 0;
     const int x0 = active ? (tid - y * C::STRIPS) * PX : 0;
     const int px = y * W + x0;
-    for (int i = tid; i < WORK; i += C::NTHREADS) lds[i] = 0.f;    // the zero rows above / below tmp_x
+    // the zero rows above / below each tmp_x plane (column-pass halo; everything else is written before it is read -- round 6: the whole 61 KB
+    // region used to be cleared, 27 ds_write_b32 per thread)
+#ifndef MM_PW_CLEAR_ALL
+#define MM_PW_CLEAR_ALL 0       // 1: clear the whole working region (round-3 form), for the A/B
+#endif
+    if (MM_PW_CLEAR_ALL) {
+        for (int i = tid; i < WORK; i += C::NTHREADS) lds[i] = 0.f;
+    } else {
+        for (int i = tid; i < F * 2 * R * W; i += C::NTHREADS) {
+            const int f = i / (2 * R * W), r = i - f * (2 * R * W);
+            tmp_x[f * C::TMP_PLANE + (r < R * W ? r : (W + R) * W + (r - R * W))] = 0.f;
+        }
+        if (tid < F * 2 * PADX) in_x[(tid / (2 * PADX)) * C::IN_PLANE + W * W + tid % (2 * PADX)] = 0.f;   // the slack row_pass_pre reads as zero padding
+    }
+    int roff[(PX + 2 * PADX) / 4];                  // this thread's five row-pass chunks: loop constants
+    row_chunk_offsets<W>(y, x0, roff);
     if (tid == 0) first_wrap = P;
     const float TWO_PI_F = 6.28318530717958647692f, PI_F = 3.14159265358979323846f;
     // ---- A
@@ -356,7 +421,11 @@ __device__ __forceinline__ void phase_window2s_body(const float* __restrict__ fr
             for (int f = 0; f < F; ++f) {
                 if (base + f > K0 + KN) continue;
                 float h[PX];
+#if MM_PW_ROW_PRE
+                row_pass_pre<W>(in_x + f * C::IN_PLANE, roff, h);
+#else
                 row_pass<W>(in_x + f * C::IN_PLANE, y, x0, h);
+#endif
                 *reinterpret_cast<float4*>(tmp_x + f * C::TMP_PLANE + (y + R) * W + x0) = float4{h[0], h[1], h[2], h[3]};
                 if (NH != 1) __builtin_amdgcn_sched_barrier(0);       // one frame's 20-float row window at a time (registers)
             }
@@ -386,9 +455,14 @@ __device__ __forceinline__ void phase_window2s_body(const float* __restrict__ fr
 #pragma unroll
     for (int k = 0; k < KN; ++k) {
         float v = active ? (d[k][0] + d[k][1]) + (d[k][2] + d[k][3]) : 0.f;
+#if MM_PW_DPP_REDUCE
+        v = wave_sum_lane63(v);
+        if (lane == 63) red[wave * (P - 1) + k] = v;
+#else
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
         if (lane == 0) red[wave * (P - 1) + k] = v;
+#endif
     }
     __syncthreads();                      // also: every blur read of the planes is done, they become the store staging
     constexpr int NWAVES = C::NTHREADS / 64;
