@@ -41,6 +41,9 @@ using namespace blur;
 #endif                          // select left in the frame loop (260 fewer vector instructions per thread).  Measured SLOWER (0.550 vs 0.510 ms,
                                 // profiles/r06_ab_phase_window_micro.txt): the lanes that read the shared zero slot conflict with the row reads
                                 // of their neighbours; the selects are cheaper than that.  Bit-identical either way.
+#ifndef MM_PW_MEAN_LANES
+#define MM_PW_MEAN_LANES 1      // 0: every thread adds all 9 x 12 partial sums itself (round-3 form), for the A/B
+#endif
 #ifndef MM_PW_DPP_REDUCE
 #define MM_PW_DPP_REDUCE 1      // 0: the round-3 __shfl_down tree (result in lane 0), for the A/B
 #endif
@@ -48,6 +51,19 @@ template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ float dpp_add(float v) {
     const int moved = __builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xf, false);
     return v + __int_as_float(moved);
+}
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ int dpp_min(int v) {
+    return min(v, __builtin_amdgcn_update_dpp(0x7fffffff, v, CTRL, ROW_MASK, 0xf, false));
+}
+__device__ __forceinline__ int wave_min_lane63(int v) {      // minimum over the wave, in lane 63 (same path as wave_sum_lane63)
+    v = dpp_min<0x111, 0xf>(v);
+    v = dpp_min<0x112, 0xf>(v);
+    v = dpp_min<0x114, 0xf>(v);
+    v = dpp_min<0x118, 0xf>(v);
+    v = dpp_min<0x142, 0xa>(v);
+    v = dpp_min<0x143, 0xc>(v);
+    return v;
 }
 __device__ __forceinline__ float wave_sum_lane63(float v) {
     v = dpp_add<0x111, 0xf>(v);      // row_shr:1
@@ -152,10 +168,16 @@ phase_window2_kernel(const float* __restrict__ fr, const int32_t* __restrict__ i
         int mine = P;                     // first frame in which one of this thread's pixels has wrapped (counts only grow)
 #pragma unroll
         for (int i = P - 1; i >= 0; --i) mine = kb[i] != 0u ? i : mine;
+#if MM_PW_DPP_REDUCE
+        mine = wave_min_lane63(mine);
+        __syncthreads();                  // first_wrap initialised, LDS zeroed
+        if (lane == 63 && mine < P) atomicMin(&first_wrap, mine);
+#else
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) mine = min(mine, __shfl_xor(mine, off, 64));
         __syncthreads();                  // first_wrap initialised, LDS zeroed
         if (lane == 0 && mine < P) atomicMin(&first_wrap, mine);
+#endif
         __syncthreads();
     }
     const int first = first_wrap;
@@ -227,6 +249,19 @@ phase_window2_kernel(const float* __restrict__ fr, const int32_t* __restrict__ i
     constexpr int NWAVES = C::NTHREADS / 64;
     const float LIM = 5.f * PI_F;
     float mean[P - 1];
+#if MM_PW_MEAN_LANES
+    {   // lane k of every wave adds the NWAVES partial sums of plane k (same order as below), the planes' means then reach all lanes as
+        // scalars (v_readlane): 9 ds_read_b32 + 8 adds + 12 readlanes per thread instead of 27 broadcast ds_read_b128 + 96 adds
+        float part = 0.f;
+        if (lane < P - 1) {
+#pragma unroll
+            for (int w = 0; w < NWAVES; ++w) part += red[w * (P - 1) + lane];
+        }
+        part *= (1.0f / (W * W));
+#pragma unroll
+        for (int k = 0; k < P - 1; ++k) mean[k] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(part), k));
+    }
+#else
 #pragma unroll
     for (int k = 0; k < P - 1; ++k) {
         float sm = 0.f;
@@ -234,6 +269,7 @@ phase_window2_kernel(const float* __restrict__ fr, const int32_t* __restrict__ i
         for (int w = 0; w < NWAVES; ++w) sm += red[w * (P - 1) + k];
         mean[k] = sm * (1.0f / (W * W));
     }
+#endif
     if (!out_nhwc) {
         if (active) {
 #pragma unroll
@@ -388,10 +424,16 @@ __device__ __forceinline__ void phase_window2s_body(const float* __restrict__ fr
         // bit, but not before frame K0
         const unsigned any = wb[0] | wb[1] | wb[2] | wb[3];
         int mine = any ? max(__builtin_ctz(any), K0) : P;
+#if MM_PW_DPP_REDUCE
+        mine = wave_min_lane63(mine);
+        __syncthreads();                  // first_wrap initialised, LDS zeroed
+        if (lane == 63 && mine < P) atomicMin(&first_wrap, mine);
+#else
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) mine = min(mine, __shfl_xor(mine, off, 64));
         __syncthreads();                  // first_wrap initialised, LDS zeroed
         if (lane == 0 && mine < P) atomicMin(&first_wrap, mine);
+#endif
         __syncthreads();
     }
     const int first = first_wrap;
@@ -468,6 +510,18 @@ __device__ __forceinline__ void phase_window2s_body(const float* __restrict__ fr
     constexpr int NWAVES = C::NTHREADS / 64;
     const float LIM = 5.f * PI_F;
     float mean[KN];
+#if MM_PW_MEAN_LANES
+    {
+        float part = 0.f;
+        if (lane < KN) {
+#pragma unroll
+            for (int w = 0; w < NWAVES; ++w) part += red[w * (P - 1) + lane];
+        }
+        part *= (1.0f / (W * W));
+#pragma unroll
+        for (int k = 0; k < KN; ++k) mean[k] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(part), k));
+    }
+#else
 #pragma unroll
     for (int k = 0; k < KN; ++k) {
         float sm = 0.f;
@@ -475,6 +529,7 @@ __device__ __forceinline__ void phase_window2s_body(const float* __restrict__ fr
         for (int w = 0; w < NWAVES; ++w) sm += red[w * (P - 1) + k];
         mean[k] = sm * (1.0f / (W * W));
     }
+#endif
     if (!out_nhwc) {
         if (active) {
 #pragma unroll
