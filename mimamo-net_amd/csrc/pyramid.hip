@@ -306,6 +306,22 @@ int pack_pyramid_tables(const PyramidTables& t, std::vector<float>& packed) {
     std::copy(t.m1[1].begin(), t.m1[1].end(), packed.begin() + OFF_M1B1);
     std::copy(t.m2[0].begin(), t.m2[0].end(), packed.begin() + OFF_M2B0);
     std::copy(t.m2[1].begin(), t.m2[1].end(), packed.begin() + OFF_M2B1);
+    // fragment order for pyramid_wave.hip (pyramid_tables.h): band 0 [r][fv] as is, band 1 [fu][c] read transposed
+    for (int level = 1; level <= 2; ++level) {
+        const int H = level == 1 ? 48 : 24, KS = H / 4, NTR = 2 * H / 16;
+        for (int band = 0; band < 2; ++band) {
+            const std::vector<float>& m = level == 1 ? t.m1[band] : t.m2[band];
+            float* dst = packed.data() + (level == 1 ? (band ? OFF_F1B1 : OFF_F1B0) : (band ? OFF_F2B1 : OFF_F2B0));
+            for (int tr = 0; tr < NTR; ++tr)
+                for (int ks = 0; ks < KS; ++ks)
+                    for (int lane = 0; lane < 64; ++lane) {
+                        const int row = 16 * tr + frag_row(lane & 15), col = 4 * ks + (lane >> 4);
+                        const size_t src = band == 0 ? (size_t)row * H + col : (size_t)col * 2 * H + row;
+                        dst[((tr * KS + ks) * 64 + lane) * 2] = m[2 * src];
+                        dst[((tr * KS + ks) * 64 + lane) * 2 + 1] = m[2 * src + 1];
+                    }
+        }
+    }
     return MM_OK;
 }
 

@@ -405,9 +405,22 @@ int64_t phase_frames_floats(int W, int64_t n) {
     return n * 2 * (W == 48 ? blur::Cfg<48>::FRAME_FLOATS : blur::Cfg<24>::FRAME_FLOATS);
 }
 
+int launch_pyramid_waves(const mm_pyramid* h, const float* frames, int64_t n, float* f1, float* f2, hipStream_t stream);   // pyramid_wave.hip
+
 // frames [n][48][48] -> frame planes of both levels (the whole per-unique-frame part of the fused phase stage)
 int launch_pyramid_frames(const mm_pyramid* h, const float* frames, int64_t n, float* f1, float* f2, hipStream_t stream) {
     if (n <= 0) return MM_OK;
+    // round 6: one wave per frame (pyramid_wave.hip) is the shipped form; MM_PF_WAVE=0 (read per call: a test switches it) runs the
+    // round-3 three-wave-workgroup kernel below, whose planes the new one reproduces bit for bit
+    const char* pf_wave = getenv("MM_PF_WAVE");
+    if (!pf_wave || atoi(pf_wave) != 0) {
+        prof_before(1, (double)n * (pyr::S * pyr::S * 4), stream, "pyramid_frame");
+        const int rc = launch_pyramid_waves(h, frames, n, f1, f2, stream);
+        prof_after(1, stream);
+        if (rc != MM_OK) return rc;
+        MM_LAUNCH_CHECK();
+        return MM_OK;
+    }
     // MM_PF_LDS_PAD / MM_PF_ABLATE (attribution of the kernel's time to its parts; results wrong by construction) exist only in a
     // library built with -DMM_MEASURE (tools/ scripts); the default build ignores the variables and always runs the full kernel
 #ifdef MM_MEASURE
