@@ -319,6 +319,8 @@ int pack_pyramid_tables(const PyramidTables& t, std::vector<float>& packed) {
                         const size_t src = band == 0 ? (size_t)row * H + col : (size_t)col * 2 * H + row;
                         dst[((tr * KS + ks) * 64 + lane) * 2] = m[2 * src];
                         dst[((tr * KS + ks) * 64 + lane) * 2 + 1] = m[2 * src + 1];
+                        if (level == 1 && (tr == 0 || tr == NTR - 1) && ks >= KS - EDGE_ZERO_KSTEPS && (m[2 * src] != 0.f || m[2 * src + 1] != 0.f))
+                            return MM_ERR_INVALID_ARG;      // pyramid_wave.hip skips these k-steps
                     }
         }
     }

@@ -24,6 +24,10 @@ constexpr int OFF_F2B0 = OFF_F1B1 + 96 * 48 * 2;    // [3][6][64][2]
 constexpr int OFF_F2B1 = OFF_F2B0 + 48 * 24 * 2;    // [3][6][64][2]
 constexpr int TABLE_FLOATS = OFF_F2B1 + 48 * 24 * 2;
 
+// Level-1 band spectra vanish beyond radius 48: in tile rows 0 and 5 of the fragment-ordered masks the last EDGE_ZERO_KSTEPS k-steps (columns
+// 36..47) are exactly zero -- pack_pyramid_tables refuses tables for which that does not hold.
+constexpr int EDGE_ZERO_KSTEPS = 3;
+
 // Row a lane supplies inside a 16-row tile when the product's accumulator is used directly as an operand of the next MFMA: accumulator
 // register e of lane (li, lk) holds row 4 lk + e, and k-slot lk of the next product's step e must be row 4 e + lk (ascending k, the
 // order of the round-3 kernels), so lane li = 4 a + b loads row 4 b + a.

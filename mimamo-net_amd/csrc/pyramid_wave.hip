@@ -130,10 +130,20 @@ template <int H> __device__ __forceinline__ int af_of(int k) { int f = k - H; f 
 //        Z[x][y] = sum_r F[.][r] T[r][.]      the kept quadrant, held TRANSPOSED (rows x): the row pass of the blur contracts over x
 //      16 rows of r at a time: T of the tile (registers) is consumed by the second product at once.  The MFMA order inside a complex
 //      step is pyramid_frames.hip's for the same output element (band 1 is that kernel's band 1 with the operand roles swapped).
-template <int H, int BAND>
+template <int H>
+__device__ __forceinline__ void load_masks(const float2* __restrict__ mfrag, int tr, int lane, float2 (&m)[H / 4]) {
+    const float2* mp = mfrag + (size_t)(tr * (H / 4)) * 64 + lane;
+#pragma unroll
+    for (int ks = 0; ks < H / 4; ++ks) m[ks] = mp[ks * 64];
+}
+
+// m: the mask fragments of tile row 0, loaded by the caller (during the previous band's epilogue); the next tile row's are fetched under
+// this one's second product.  prefetch_next() is called between the products and the epilogue (the next band's first fragments).
+template <int H, int BAND, class Prefetch>
 __device__ __forceinline__ void band(const float* ec, const float* es, const float* g, float* sc, const float2* __restrict__ mfrag,
-                                     float* __restrict__ o, int lane, const Lane& L) {
+                                     float* __restrict__ o, int lane, const Lane& L, float2 (&m)[H / 4], Prefetch&& prefetch_next) {
     constexpr int STEP = S / H, MT = (H + 15) / 16, NTR = 2 * H / 16, KS = H / 4, PLANE = H * H;
+    constexpr int KS_ZERO = H == 48 ? EDGE_ZERO_KSTEPS : 0;
     const int li = L.li, lk = L.lk, pli = L.pli;
     f32x4 zre[MT][MT], zim[MT][MT];      // [x tile][y tile]; register e of lane (li, lk): x = 16 tx + 4 e + lk, y = 16 ty + li
     zero(zre);
@@ -146,15 +156,13 @@ __device__ __forceinline__ void band(const float* ec, const float* es, const flo
         fa = fa < 0 ? -fa : fa;                                    // |frequency| <= 48; 48 reads G's zero border
         const int gbase = BAND == 0 ? fa * LD + lk : lk * LD + fa;
         constexpr int GSTEP = BAND == 0 ? 4 : 4 * LD;
-        const float2* mp = mfrag + (size_t)(tr * KS) * 64 + lane;
-        float2 m[KS];
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) m[ks] = mp[ks * 64];
         f32x4 tre[MT], tim[MT];
         zero(tre);
         zero(tim);
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
+        // level 1: the spectrum is zero beyond radius 48, i.e. in the last KS_ZERO k-steps of the first and the last tile row (checked when
+        // the tables are packed): exact zeros into a fused multiply-add chain, skipped
+        const bool edge = KS_ZERO > 0 && (tr == 0 || tr == NTR - 1);
+        auto kstep = [&](int ks) {
             const float gv = g[gbase + ks * GSTEP];
             const float a_r = gv * m[ks].x, a_i = gv * m[ks].y, na_i = -a_i;
 #pragma unroll
@@ -172,7 +180,14 @@ __device__ __forceinline__ void band(const float* ec, const float* es, const flo
                     tim[tj] = mfma4(a_r, b_i, tim[tj]);
                 }
             }
+        };
+#pragma unroll
+        for (int ks = 0; ks < KS - KS_ZERO; ++ks) kstep(ks);
+        if (KS_ZERO > 0 && !edge) {
+#pragma unroll
+            for (int ks = KS - KS_ZERO; ks < KS; ++ks) kstep(ks);
         }
+        load_masks<H>(mfrag, tr + 1 < NTR ? tr + 1 : tr, lane, m);      // (the last one again: no branch)
         // second product over this tile's 16 values of r: step e covers r = 16 tr + 4 e + lk
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -209,27 +224,36 @@ __device__ __forceinline__ void band(const float* ec, const float* es, const flo
             }
         }
     }
-    // ---- polar: phase and magnitude are final (stored); (re, im) -> (mag phase, mag) in place
-    // (store offsets: one opaque 32-bit base per band + constants, or hipcc keeps a 64-bit index pair per pixel alive across the four bands)
-    unsigned sb_in = (unsigned)(li * H + lk), sb_out = (unsigned)(4 * lk * H + li);
+    prefetch_next();
+    // ---- polar: phase and magnitude are final (stored); (re, im) -> (mag phase, mag) in place.  Level 2 computes 32 x 32: columns x >= 24
+    //      (whole registers) are skipped, rows y >= 24 (lanes) are computed and not stored.
+    // (store addresses: one opaque per-lane pointer per band + constants, or hipcc keeps a 64-bit index pair per pixel alive across the bands)
+    int sb_in = li * H + lk, sb_out = 4 * lk * H + li;
     asm volatile("" : "+v"(sb_in), "+v"(sb_out));
+    float* const o_in = o + sb_in;
+    float* const o_out = o + sb_out;
 #pragma unroll
     for (int tx = 0; tx < MT; ++tx)
 #pragma unroll
         for (int ty = 0; ty < MT; ++ty) {
+            const bool rows_ok = 16 * ty + 16 <= H || 16 * ty + li < H;
+            float ph[4], mg[4];
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                const int x = 16 * tx + 4 * e + lk, y = 16 * ty + li;
-                float ph, mg;
-                to_polar(zre[tx][ty][e], zim[tx][ty][e], ph, mg);
-                if (H % 16 == 0 || (x < H && y < H)) {
-                    o[sb_in + (unsigned)(16 * ty * H + 16 * tx + 4 * e)] = mg;
-                    o[sb_in + (unsigned)(3 * PLANE + 16 * ty * H + 16 * tx + 4 * e)] = ph;
-                }
-                zre[tx][ty][e] = mg * ph;
-                zim[tx][ty][e] = mg;
+                if (16 * tx + 4 * e >= H) continue;
+                to_polar(zre[tx][ty][e], zim[tx][ty][e], ph[e], mg[e]);
+                zre[tx][ty][e] = mg[e] * ph[e];
+                zim[tx][ty][e] = mg[e];
             }
-            __builtin_amdgcn_sched_barrier(0);      // four pixels at a time: the scheduler otherwise interleaves all 36 and spills
+            if (rows_ok) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    if (16 * tx + 4 * e >= H) continue;
+                    o_in[16 * ty * H + 16 * tx + 4 * e] = mg[e];
+                    o_in[3 * PLANE + 16 * ty * H + 16 * tx + 4 * e] = ph[e];
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);      // four pixels at a time: the scheduler otherwise interleaves all 36
         }
     // ---- blur, one 16-column strip of the output at a time: rows (contract x', from the registers), hand over through LDS,
     //      columns (contract y'), divide, store
@@ -245,6 +269,7 @@ __device__ __forceinline__ void band(const float* ec, const float* es, const flo
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 if (16 * ti + 4 * e >= H) continue;                // beyond the plane: zero padding, nothing to add
+                if ((ti < tx && e < 2) || (ti > tx && e >= 2)) continue;   // more than five columns away: K is zero on the whole block
                 const float kf = L.kf1[tx - ti + 1][e];
 #pragma unroll
                 for (int ty = 0; ty < MT; ++ty) {
@@ -273,15 +298,18 @@ __device__ __forceinline__ void band(const float* ec, const float* es, const flo
                 d2[pt] = mfma4(L.kf2[s], sc_d[li * LD + k0 + lk], d2[pt]);
             }
 #pragma unroll
-        for (int pt = 0; pt < MT; ++pt)
+        for (int pt = 0; pt < MT; ++pt) {
+            // register e of lane (li, lk): y = 16 pt + 4 lk + e, x = 16 tx + li
+            const bool ok = (16 * tx + 16 <= H || 16 * tx + li < H) && (16 * pt + 16 <= H || 16 * pt + 4 * lk + 3 < H);
+            static_assert(H % 4 == 0, "a lane's four rows are inside or outside together");
+            if (ok) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int y = 16 * pt + 4 * lk + e, x = 16 * tx + li;
-                if (H % 16 == 0 || (x < H && y < H)) {
-                    o[sb_out + (unsigned)(PLANE + (16 * pt + e) * H + 16 * tx)] = n2[pt][e] / d2[pt][e];
-                    o[sb_out + (unsigned)(2 * PLANE + (16 * pt + e) * H + 16 * tx)] = 1.0f / d2[pt][e];
+                for (int e = 0; e < 4; ++e) {
+                    o_out[PLANE + (16 * pt + e) * H + 16 * tx] = n2[pt][e] / d2[pt][e];
+                    o_out[2 * PLANE + (16 * pt + e) * H + 16 * tx] = 1.0f / d2[pt][e];
                 }
             }
+        }
         wave_lds_fence();
     }
 }
@@ -331,13 +359,16 @@ pyramid_wave_kernel(const float* __restrict__ tables, const float* __restrict__ 
         L.li = lane_ & 15;
         L.lk = lane_ >> 4;
         L.pli = frag_row(L.li);
+        float2 m48[12], m24[6];
+        load_masks<48>(t2 + OFF_F1B0 / 2, 0, lane_, m48);
         dct_stage(frames + img * (S * S), dct, g, L);
         float* o1 = f1 + img * (2 * Cfg<48>::FRAME_FLOATS);
         float* o2 = f2 + img * (2 * Cfg<24>::FRAME_FLOATS);
-        band<48, 0>(ec, es, g, sc, t2 + OFF_F1B0 / 2, o1, lane_, L);
-        band<24, 0>(ec, es, g, sc, t2 + OFF_F2B0 / 2, o2, lane_, L);
-        band<48, 1>(ec, es, g, sc, t2 + OFF_F1B1 / 2, o1 + Cfg<48>::FRAME_FLOATS, lane_, L);
-        band<24, 1>(ec, es, g, sc, t2 + OFF_F2B1 / 2, o2 + Cfg<24>::FRAME_FLOATS, lane_, L);
+        band<48, 0>(ec, es, g, sc, t2 + OFF_F1B0 / 2, o1, lane_, L, m48, [&]() { load_masks<24>(t2 + OFF_F2B0 / 2, 0, lane_, m24); });
+        band<24, 0>(ec, es, g, sc, t2 + OFF_F2B0 / 2, o2, lane_, L, m24, [&]() { load_masks<48>(t2 + OFF_F1B1 / 2, 0, lane_, m48); });
+        band<48, 1>(ec, es, g, sc, t2 + OFF_F1B1 / 2, o1 + Cfg<48>::FRAME_FLOATS, lane_, L, m48,
+                    [&]() { load_masks<24>(t2 + OFF_F2B1 / 2, 0, lane_, m24); });
+        band<24, 1>(ec, es, g, sc, t2 + OFF_F2B1 / 2, o2 + Cfg<24>::FRAME_FLOATS, lane_, L, m24, []() {});
     }
 }
 

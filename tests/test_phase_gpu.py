@@ -153,6 +153,52 @@ def test_fast_path_takes_any_window_pattern(pde, dev):
         pde.phase_diff_frames(f, ids + 50)
 
 
+def _frame_planes(pde, frames, ids):
+    """phase_diff_frames, then the per-frame planes {mag, B, R, phase} it left in its workspace (level 1 [n,2,4,48,48], level 2 [n,2,4,24,24])."""
+    p0, p1 = pde.phase_diff_frames(frames, ids, ids_checked=True)
+    torch.cuda.synchronize()
+    ws = pde._ws[torch.cuda.current_stream().cuda_stream]
+    n = frames.shape[0]
+    n1 = n * 2 * 4 * 48 * 48
+    return (ws[:n1].view(n, 2, 4, 48, 48).clone(), ws[n1:n1 + n * 2 * 4 * 24 * 24].view(n, 2, 4, 24, 24).clone(), p0.clone(), p1.clone())
+
+
+def test_wave_per_frame_kernel_reproduces_the_three_wave_kernel_bit_for_bit(pde, dev, monkeypatch):
+    """Round 6: pyramid_wave_kernel (csrc/pyramid_wave.hip: one wave owns a frame, accumulators feed the next MFMA as operands, band masks
+    in fragment order, both blurs on the matrix pipe) against the round-3 pyramid_frame_kernel (MM_PF_WAVE=0) that the goldens have
+    pinned since: same operand values into the same fused multiply-add chains in the same k order, so ALL FOUR planes per (frame,
+    band, level) -- magnitude, blur(mag phase) / blur(mag), 1 / blur(mag), phase -- carry the same bits, and with them every phase
+    difference.  Sizes: every workgroup shape of the new kernel forced on small batches (MM_PF_WAVE=2: 1 / 2 / 4 / 8 waves per
+    workgroup, ragged last workgroup), the shipped split (MM_PF_WAVE unset: whole rounds of 2 048 frames on the wave kernel, a remainder
+    up to 512 frames on the three-wave kernel, a larger one on the wave kernel), and degenerate frames (constant, zero, huge range)."""
+    rng = np.random.RandomState(5)
+    base = np.concatenate([synthetic.textured_gray(64, 48, seed=600 + c) for c in range(4)])
+
+    def batch(n):
+        f = torch.from_numpy(base[np.arange(n) % base.shape[0]].copy()).to(dev)
+        f[1::7] += torch.from_numpy(rng.rand(len(range(1, n, 7)), 48, 48).astype(np.float32)).to(dev)      # no two frames alike
+        if n >= 8:
+            f[3] = 0.0
+            f[4] = 7.5
+            f[5] *= 1e4
+        ids = torch.clamp(torch.arange(n, device=dev)[:, None] + torch.arange(-6, 7, device=dev)[None, :], 0, n - 1).int().contiguous()
+        return f.contiguous(), ids
+    for n, mode in ((1, "2"), (13, "2"), (64, "2"), (257, "2"), (300, "2"), (513, None), (1030, None), (2048, None), (2048 + 77, None),
+                    (2048 + 600, None)):
+        f, ids = batch(n)
+        monkeypatch.setenv("MM_PF_WAVE", "0")
+        ref = _frame_planes(pde, f, ids)
+        if mode is None:
+            monkeypatch.delenv("MM_PF_WAVE")
+        else:
+            monkeypatch.setenv("MM_PF_WAVE", mode)
+        got = _frame_planes(pde, f, ids)
+        monkeypatch.delenv("MM_PF_WAVE", raising=False)
+        for k, (a, b) in enumerate(zip(ref, got)):
+            assert a.shape == b.shape and torch.isfinite(b[:3]).all() if k >= 2 else a.shape == b.shape
+            assert torch.equal(a.view(torch.int32), b.view(torch.int32)), (n, mode, k, (a - b).abs().max().item(), int((a != b).sum()))
+
+
 def test_time_split_window_kernel_equals_the_one_workgroup_form(pde, dev, monkeypatch):
     """Round 6 (verdict item 3b), built and measured SLOWER (profiles/r06_ab_phase_window_split.txt), kept opt-in as MM_PW_SPLIT=2:
     phase_window2s_kernel runs TWO workgroups per (window, band), each owning six of the twelve difference planes (split along time: the
