@@ -104,8 +104,10 @@ def measure_live_traffic(args, per_step):
         return {"error": "rocprofv3 not found"}
     steps, warm = 1, 1
     groups = {"conv": ("conv_mfma_kernel", "wino_fused_kernel"), "winograd_transforms": ("wino_in", "wino_out"),
-              "phase": ("pyramid_frame_kernel", "pyramid_kernel", "phase_window2_kernel")}
-    phase_kernels = {"pyramid_frame": "pyramid_frame_kernel", "phase_window2<48>": "phase_window2_kernel<48", "phase_window2<24>": "phase_window2_kernel<24"}
+              "phase": ("pyramid_wave_kernel", "pyramid_frame_kernel", "pyramid_kernel", "phase_window2_kernel")}
+    # (the per-frame stage is pyramid_wave_kernel for whole rounds of 2 048 frames, pyramid_frame_kernel for a small remainder: one tag)
+    phase_kernels = {"pyramid_frame": ("pyramid_wave_kernel", "pyramid_frame_kernel"), "phase_window2<48>": "phase_window2_kernel<48",
+                     "phase_window2<24>": "phase_window2_kernel<24"}
     tot = {g: {} for g in groups}
     tmp = None
     try:
@@ -190,7 +192,7 @@ def sq_pass_summary(counter_csv, trace_csv, nsteps, conv_pats, phase_kernels):
                 elif c == "SQ_VALU_MFMA_BUSY_CYCLES":
                     busy += v
             for t, pat in phase_kernels.items():
-                if pat in name:
+                if any(p_ in name for p_ in ((pat,) if isinstance(pat, str) else pat)):
                     if c == "SQ_INSTS_VALU":
                         valu[t] += v
                     elif c == "SQ_INSTS_MFMA":
@@ -214,7 +216,9 @@ def phase_floors(live_rows, n_frames, valu_insts=None):
     measurement hook; valu_insts: {tag: non-MFMA VALU wave instructions per step} from the live SQ pass, or None.
       floor_hbm_ms  = the kernel's algorithmic bytes / 8 TB/s (pyramid: frame in + the four planes per (frame, band, level) it hands to
                       the window kernels are INTERNAL traffic, not counted; windows: the difference planes written)
-      floor_mfma_ms = pyramid only: 4 344 v_mfma_f32_16x16x4_f32 = 8.9 MFLOP per frame / 157.3 TFLOP/s
+      floor_mfma_ms = pyramid only: the 4 344 v_mfma_f32_16x16x4_f32 = 8.9 MFLOP per frame of the pyramid products / 157.3 TFLOP/s
+                      (pyramid_wave_kernel EXECUTES 4 840: 144 exact-zero spectrum blocks skipped, 640 added by the blurs it runs on the
+                      matrix pipe instead of the vector pipe -- the floor stays the algorithm's)
       floor_valu_ms = VALU wave instructions x 4 issue cycles / 1 024 SIMDs / 2.4 GHz (a wave64 VALU instruction occupies its SIMD 4 cycles)
     A kernel's floor is the largest of its floors; the stage's limiting floor is the SUM of the kernels' floors (they run back to back)."""
     kern = {}

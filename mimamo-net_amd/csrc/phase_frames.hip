@@ -90,6 +90,47 @@ __device__ __forceinline__ float wave_sum_lane63(float v) {
 //      stride on all eight
 // F = frames per barrier round (three barriers each).  A 9-wave workgroup at ~160 registers is alone on its CU, so the whole
 // 160 KB of LDS is its to use: F planes of blur input + row-pass output.
+// Row-pass input planes of phase_window2_kernel (round 6): every row carries eight zero floats on both sides -- the blur's zero padding is IN
+// the plane and the row pass is five unconditional 16-byte reads.  Rounds 3-5: 20 v_cndmask per frame and thread on the chunk addresses and
+// values, and hipcc narrowed the outer chunks to b32 / b96 reads whose lane groups conflict (PMC SQ_LDS_BANK_CONFLICT 2.7e7 -> 1.8e6 per
+// launch of <48>, window kernels -9.5 % same-box: profiles/r06_ab_phase_window_pad.txt).  Row stride 112 (W = 48) / 88 (W = 24) floats = the
+// dense stride mod 64: the sixteen lanes of a ds_read_b128 group still fall on sixteen different 16-byte bank groups, as in the dense plane.
+#ifndef MM_PW_PAD_ROWS
+#define MM_PW_PAD_ROWS 1        // 0: dense planes + selects (rounds 3-5), for the A/B
+#endif
+#ifndef MM_PW_PAD_ROWS_24
+#define MM_PW_PAD_ROWS_24 1     // 0: W = 24 stays dense (measured equal either way), for the A/B
+#endif
+template <int W> struct PwIn {
+    static constexpr bool PADDED = MM_PW_PAD_ROWS && (W == 48 || MM_PW_PAD_ROWS_24);
+    static constexpr int STRIDE = PADDED ? (W == 48 ? 112 : 88) : W;      // 4 x (12 | 6 strips + 16 k)
+    static constexpr int LEFT = PADDED ? PADX : 0;
+    static constexpr int PLANE = PADDED ? (W - 1) * STRIDE + W + 2 * PADX : Cfg<W>::IN_PLANE;
+};
+template <int W> struct PwDense {
+    static constexpr bool PADDED = false;
+    static constexpr int STRIDE = W, LEFT = 0, PLANE = Cfg<W>::IN_PLANE;
+};
+template <int W>
+__device__ __forceinline__ void row_pass_padded(const float* row_x0, float (&h)[PX]) {      // row_x0: the row's padded start + x0, i.e. pixel x0 - 8
+    float v[PX + 2 * PADX];
+#pragma unroll
+    for (int q = 0; q < (PX + 2 * PADX) / 4; ++q) {
+        float4 a = *reinterpret_cast<const float4*>(__builtin_assume_aligned(row_x0 + 4 * q, 16));
+        // (only v[3..16] are used: left alone, hipcc shrinks the outer chunks and re-forms the 14 floats as seven ds_read2_b32, whose 32-lane
+        //  groups conflict on this row stride -- keep the five 16-byte reads)
+        asm volatile("" : "+v"(a.x), "+v"(a.y), "+v"(a.z), "+v"(a.w));
+        v[4 * q] = a.x; v[4 * q + 1] = a.y; v[4 * q + 2] = a.z; v[4 * q + 3] = a.w;
+    }
+#pragma unroll
+    for (int p = 0; p < PX; ++p) {
+        float s = 0.f;
+#pragma unroll
+        for (int t = 0; t < TAP; ++t) s = fmaf(c_g[t], v[PADX - R + p + t], s);
+        h[p] = s;
+    }
+}
+
 template <int W, int F>
 __global__ void __launch_bounds__(Cfg<W>::NTHREADS)
 phase_window2_kernel(const float* __restrict__ fr, const int32_t* __restrict__ ids, int n_frames, float* __restrict__ out, int out_nhwc,
@@ -97,7 +138,9 @@ phase_window2_kernel(const float* __restrict__ fr, const int32_t* __restrict__ i
     using C = Cfg<W>;
     constexpr int RPG = W == 48 ? 16 : 12;                    // rows per store group: RPG * W * 12 floats staged at a time
     constexpr int G = W / RPG;
-    constexpr int WORK = F * (C::IN_PLANE + C::TMP_PLANE);
+    using PW = PwIn<W>;
+    constexpr int IN_PLANE_ = PW::PLANE;
+    constexpr int WORK = F * (IN_PLANE_ + C::TMP_PLANE);
 #ifndef MM_PW_STAGE_PAD
 #define MM_PW_STAGE_PAD 1                                     // 0: the round-4 staging (12-slot thread blocks), for the A/B
 #endif
@@ -106,17 +149,18 @@ phase_window2_kernel(const float* __restrict__ fr, const int32_t* __restrict__ i
     extern __shared__ __attribute__((aligned(16))) float lds[];      // WORK + 64 * (P - 1) floats + first_wrap
     int& first_wrap = *reinterpret_cast<int*>(lds + WORK + 64 * (P - 1));
     float* in_x = lds;                              // [F][IN_PLANE]
-    float* tmp_x = in_x + F * C::IN_PLANE;          // [F][TMP_PLANE]
+    float* tmp_x = in_x + F * IN_PLANE_;            // [F][TMP_PLANE]
     float* red = lds + WORK;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // consecutive windows share 12 of their 13 frames: keep them on one XCD (one L2) instead of spreading them over all eight
     const int logical = xcd_contiguous(blockIdx.x, gridDim.x);
     const int64_t j = logical >> 1;
     const int band = logical & 1;
-    const bool active = tid < C::ACTIVE;
+    const bool active = C::ACTIVE == C::NTHREADS || tid < C::ACTIVE;      // (W = 48: every thread -- no exec-mask branches)
     const int y = active ? tid / C::STRIPS : 0;
     const int x0 = active ? (tid - y * C::STRIPS) * PX : 0;
     const int px = y * W + x0;
+    const int ipx = y * PW::STRIDE + PW::LEFT + x0;      // the pixel strip in a row-pass input plane
     // the zero rows above / below each tmp_x plane (column-pass halo; everything else is written before it is read -- round 6: the whole 61 KB
     // region used to be cleared, 27 ds_write_b32 per thread)
 #ifndef MM_PW_CLEAR_ALL
@@ -129,7 +173,13 @@ phase_window2_kernel(const float* __restrict__ fr, const int32_t* __restrict__ i
             const int f = i / (2 * R * W), r = i - f * (2 * R * W);
             tmp_x[f * C::TMP_PLANE + (r < R * W ? r : (W + R) * W + (r - R * W))] = 0.f;
         }
-        if (tid < F * 2 * PADX) in_x[(tid / (2 * PADX)) * C::IN_PLANE + W * W + tid % (2 * PADX)] = 0.f;   // the slack row_pass_pre reads as zero padding
+        if (!PW::PADDED && tid < F * 2 * PADX) in_x[(tid / (2 * PADX)) * IN_PLANE_ + W * W + tid % (2 * PADX)] = 0.f;   // the slack row_pass_pre reads as zero padding
+        if (PW::PADDED) {                   // the eight zero floats left and right of every row of the F input planes: one 16-byte store per thread
+            for (int i = tid; i < F * W * 4; i += C::NTHREADS) {
+                const int f = i / (W * 4), r = (i >> 2) % W, q = i & 3;
+                *reinterpret_cast<float4*>(in_x + f * IN_PLANE_ + r * PW::STRIDE + (q < 2 ? 4 * q : W + PADX + 4 * (q - 2))) = float4{0.f, 0.f, 0.f, 0.f};
+            }
+        }
     }
     int roff[(PX + 2 * PADX) / 4];                  // this thread's five row-pass chunks: loop constants
     row_chunk_offsets<W>(y, x0, roff);
@@ -195,7 +245,7 @@ phase_window2_kernel(const float* __restrict__ fr, const int32_t* __restrict__ i
             const float4 m4 = *reinterpret_cast<const float4*>(fo[i] + px);
             r4[f] = *reinterpret_cast<const float4*>(fo[i] + 2 * C::PLANE + px);    // a pixel's blur also sums its neighbours' wraps
             const unsigned k = kb[i];
-            *reinterpret_cast<float4*>(in_x + f * C::IN_PLANE + px) =
+            *reinterpret_cast<float4*>(in_x + f * IN_PLANE_ + ipx) =
                 float4{m4.x * (-TWO_PI_F * (float)(k & 255u)), m4.y * (-TWO_PI_F * (float)((k >> 8) & 255u)),
                        m4.z * (-TWO_PI_F * (float)((k >> 16) & 255u)), m4.w * (-TWO_PI_F * (float)(k >> 24))};
         }
@@ -206,9 +256,10 @@ phase_window2_kernel(const float* __restrict__ fr, const int32_t* __restrict__ i
                 if (base + f >= P) continue;
                 float h[PX];
 #if MM_PW_ROW_PRE
-                row_pass_pre<W>(in_x + f * C::IN_PLANE, roff, h);
+                row_pass_pre<W>(in_x + f * IN_PLANE_, roff, h);
 #else
-                row_pass<W>(in_x + f * C::IN_PLANE, y, x0, h);
+                if (PW::PADDED) row_pass_padded<W>(in_x + f * IN_PLANE_ + y * PW::STRIDE + x0, h);
+                else row_pass<W>(in_x + f * IN_PLANE_, y, x0, h);
 #endif
                 *reinterpret_cast<float4*>(tmp_x + f * C::TMP_PLANE + (y + R) * W + x0) = float4{h[0], h[1], h[2], h[3]};
             }
@@ -589,7 +640,7 @@ template <int W, int F>
 static int launch_w2(const float* fr, const int32_t* ids, int n, int64_t J, float* out, int out_nhwc, int out_cstride, int out_coffset,
                      hipStream_t s) {
     using C = Cfg<W>;
-    const int lds_bytes = (F * (C::IN_PLANE + C::TMP_PLANE) + 64 * (P - 1) + 4) * 4;
+    const int lds_bytes = (F * (PwIn<W>::PLANE + C::TMP_PLANE) + 64 * (P - 1) + 4) * 4;
     MM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(phase_window2_kernel<W, F>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                lds_bytes));
     hipLaunchKernelGGL((phase_window2_kernel<W, F>), dim3((unsigned)(2 * J)), dim3(C::NTHREADS), lds_bytes, s, fr, ids, n, out, out_nhwc,

@@ -416,12 +416,14 @@ def test_sq_pass_summary_and_phase_floors(tmp_path):
             ("void mm::wino_fused_kernel<3,2>(p)", "GRBM_GUI_ACTIVE", 8 * 1.0e6), ("void mm::wino_fused_kernel<3,2>(p)", "SQ_VALU_MFMA_BUSY_CYCLES", 0.6 * 1024 * 1.0e6),
             ("void mm::phase_window2_kernel<48>(a)", "SQ_INSTS_VALU", 2 * 8.88e7), ("void mm::phase_window2_kernel<48>(a)", "SQ_INSTS_MFMA", 0.0),
             ("void mm::phase_window2_kernel<24>(a)", "SQ_INSTS_VALU", 2 * 2.4e7),
-            ("void mm::pyramid_frame_kernel(a)", "SQ_INSTS_VALU", 2 * 5.0e7), ("void mm::pyramid_frame_kernel(a)", "SQ_INSTS_MFMA", 2 * 8.9e6),
+            ("void mm::pw::pyramid_wave_kernel<8>(a)", "SQ_INSTS_VALU", 2 * 4.0e7), ("void mm::pw::pyramid_wave_kernel<8>(a)", "SQ_INSTS_MFMA", 2 * 8.0e6),
+            ("void mm::pf::pyramid_frame_kernel(a)", "SQ_INSTS_VALU", 2 * 1.0e7), ("void mm::pf::pyramid_frame_kernel(a)", "SQ_INSTS_MFMA", 2 * 0.9e6),
             ("void mm::wino_in6_kernel(a)", "GRBM_GUI_ACTIVE", 1e9)]
     cc.write_text("Kernel_Name,Counter_Name,Counter_Value\n" + "".join('"%s",%s,%r\n' % r for r in rows))
     tr.write_text("Kernel_Name,Start_Timestamp,End_Timestamp\n"
                   '"void mm::conv_mfma_kernel<128,256>(p)",1000,1001000\n"void mm::wino_fused_kernel<3,2>(p)",2000000,2500000\n"void mm::wino_in6_kernel(a)",0,5\n')
-    pk = {"pyramid_frame": "pyramid_frame_kernel", "phase_window2<48>": "phase_window2_kernel<48", "phase_window2<24>": "phase_window2_kernel<24"}
+    # (the per-frame stage: pyramid_wave_kernel for whole rounds of 2 048 frames + pyramid_frame_kernel for a small remainder, one tag)
+    pk = {"pyramid_frame": ("pyramid_wave_kernel", "pyramid_frame_kernel"), "phase_window2<48>": "phase_window2_kernel<48", "phase_window2<24>": "phase_window2_kernel<24"}
     clock, valu = bench.sq_pass_summary(str(cc), str(tr), 2, ("conv_mfma_kernel", "wino_fused_kernel"), pk)
     assert abs(clock["GHz"] - 3.0e6 / 1.5e6) < 1e-9                      # 3.0e6 cycles in 1.5 ms = 2.0 GHz
     assert abs(clock["mfma_busy"] - (0.9 * 2 + 0.6 * 1) / 3) < 1e-9

@@ -29,7 +29,7 @@ def kernel_of(tag):
         return "wino_fused_kernel"
     if tag.startswith("M="):
         return "conv_mfma_kernel"
-    return {"phase_window2<48>": "phase_window2_kernel", "phase_window2<24>": "phase_window2_kernel", "pyramid_frame": "pyramid_frame_kernel",
+    return {"phase_window2<48>": "phase_window2_kernel", "phase_window2<24>": "phase_window2_kernel", "pyramid_frame": "pyramid_wave_kernel",
             "maxpool3x3s2": "maxpool_kernel", "maxpool+reduce64": "maxpool_reduce64_kernel", "vpool+reduce64": "maxpool_reduce64_kernel", "avgpool": "avgpool", "gru_gates": "gru_gates_kernel"}.get(tag, tag)
 
 

@@ -26,7 +26,7 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):   # ... as the profiled run itself report
             got = json.loads(line).get("hot_path_steps_executed")
             assert got == nsteps, (c, got, nsteps)
 groups = {"conv": ("conv_mfma_kernel", "wino_fused_kernel"), "winograd_transforms": ("wino_in", "wino_out"),
-          "pyramid": ("pyramid_kernel", "pyramid_frame_kernel"), "phase_frames_windows": ("phase_window2_kernel",)}
+          "pyramid": ("pyramid_kernel", "pyramid_frame_kernel", "pyramid_wave_kernel"), "phase_frames_windows": ("phase_window2_kernel",)}
 tot = {g: {} for g in groups}
 for c in ("FETCH_SIZE", "WRITE_SIZE"):
     f = glob.glob("/tmp/bt_%s/**/*counter_collection.csv" % c, recursive=True)[0]
