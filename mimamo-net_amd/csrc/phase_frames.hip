@@ -114,13 +114,17 @@ template <int W> struct PwDense {
 template <int W>
 __device__ __forceinline__ void row_pass_padded(const float* row_x0, float (&h)[PX]) {      // row_x0: the row's padded start + x0, i.e. pixel x0 - 8
     float v[PX + 2 * PADX];
+    float4 a[(PX + 2 * PADX) / 4];
+#pragma unroll
+    for (int q = 0; q < (PX + 2 * PADX) / 4; ++q) a[q] = *reinterpret_cast<const float4*>(__builtin_assume_aligned(row_x0 + 4 * q, 16));
+    // (only v[3..16] are used: left alone, hipcc shrinks the outer chunks and re-forms the 14 floats as seven ds_read2_b32, whose 32-lane
+    //  groups conflict on this row stride -- one empty asm over all five values keeps the five 16-byte reads and lets them be in flight together)
+    asm volatile("" : "+v"(a[0].x), "+v"(a[0].y), "+v"(a[0].z), "+v"(a[0].w), "+v"(a[1].x), "+v"(a[1].y), "+v"(a[1].z), "+v"(a[1].w),
+                      "+v"(a[2].x), "+v"(a[2].y), "+v"(a[2].z), "+v"(a[2].w), "+v"(a[3].x), "+v"(a[3].y), "+v"(a[3].z), "+v"(a[3].w),
+                      "+v"(a[4].x), "+v"(a[4].y), "+v"(a[4].z), "+v"(a[4].w));
 #pragma unroll
     for (int q = 0; q < (PX + 2 * PADX) / 4; ++q) {
-        float4 a = *reinterpret_cast<const float4*>(__builtin_assume_aligned(row_x0 + 4 * q, 16));
-        // (only v[3..16] are used: left alone, hipcc shrinks the outer chunks and re-forms the 14 floats as seven ds_read2_b32, whose 32-lane
-        //  groups conflict on this row stride -- keep the five 16-byte reads)
-        asm volatile("" : "+v"(a.x), "+v"(a.y), "+v"(a.z), "+v"(a.w));
-        v[4 * q] = a.x; v[4 * q + 1] = a.y; v[4 * q + 2] = a.z; v[4 * q + 3] = a.w;
+        v[4 * q] = a[q].x; v[4 * q + 1] = a[q].y; v[4 * q + 2] = a[q].z; v[4 * q + 3] = a[q].w;
     }
 #pragma unroll
     for (int p = 0; p < PX; ++p) {
