@@ -914,14 +914,14 @@ def run_rank(args):
     result["roofline"]["clock_note"] = (clk["how"] if clk else
                                         "no live SQ / GRBM pass (%s)" % ((live_traffic or {}).get("sq_pass_error") or (live_traffic or {}).get("error")
                                                                          or "not requested: --no-extra / --no-live-traffic / N > 1"))
-    # both floors of the phase stage: HBM (algorithmic bytes at 8 TB/s) and the matrix pipes (pyramid_frame_kernel: 4 344
+    # both floors of the phase stage: HBM (algorithmic bytes at 8 TB/s) and the matrix pipes (the pyramid products: 4 344
     # v_mfma_f32_16x16x4_f32 = 8.9 MFLOP per frame) -- the MFMA floor is the higher one
     ph_floor_hbm = (work_[1] + work_[2]) / (PEAK_HBM_GBS * 1e9) * 1e3
     ph_floor_mfma = n_frames * 4344 * 2048.0 / (PEAK_FP32_MFMA_TFLOPS * 1e12) * 1e3
     ph_valu = live_traffic.get("valu") if live_traffic else None
     ph_kernels, ph_floor_sum = phase_floors(live, n_frames, ph_valu)
     ph_floor_valu = sum(k.get("floor_valu_ms", 0.0) for k in ph_kernels.values()) if ph_valu else None
-    result["roofline_phase"] = {"bound": "hbm", "kernel": "pyramid_frame_kernel + phase_window2_kernel<48|24> (all phase-stage launches of one step)",
+    result["roofline_phase"] = {"bound": "hbm", "kernel": "pyramid_wave_kernel + phase_window2_kernel<48|24> (all phase-stage launches of one step)",
                                 "achieved": phase_gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": phase_gbs / PEAK_HBM_GBS,
                                 "floor_hbm_ms": ph_floor_hbm, "floor_mfma_ms": ph_floor_mfma,
                                 "floor_valu_ms": ph_floor_valu,
@@ -1109,7 +1109,7 @@ def phase_only_leg(comp):
         from mimamo_net_amd.preprocess import FramePreprocessor
         hot._pre = FramePreprocessor(phase_size=hot.phase_size, mean=hot.resnet.meta['mean'], device=dev)
     out = {"unit": "frames/s", "algorithmic_bytes_per_frame": 285696,
-           "what": "pyramid_frame_kernel + phase_window2_kernel<48|24> on gray 48x48 fp32 frames resident in HBM, 13-frame clamped windows "
+           "what": "pyramid_wave_kernel + phase_window2_kernel<48|24> on gray 48x48 fp32 frames resident in HBM, 13-frame clamped windows "
                    "of 64-frame clips, single stream (BASELINE configs[1]); GB_per_s on SURVEY 8(d)'s 285 696 B/frame"}
     pool_clips = comp.frames_u8.shape[0] // FRAMES_PER_CLIP
     with torch.no_grad():

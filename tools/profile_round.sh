@@ -17,3 +17,6 @@ bash $R/tools/layer_roofline.sh 32 > $O/r06_layer_roofline.log 2>&1      # -> r0
 # the bench line quotes the PMC traffic / per-launch byte list of the sources it runs from profiles/: put this call's files there first
 cp $O/r06_conv_traffic_32clips.json $O/r06_phase_traffic_32clips.json $O/r06_layer_bytes_32clips.json $O/r06_layer_table_32clips.txt $R/profiles/
 cd $R && python bench.py > $O/r06_bench_default.json 2> $O/r06_bench_default.err
+# phase-stage counters (three passes) of the kernels the bundle's sources ship
+bash $R/tools/pmc_phase.sh pyramid_wave_kernel 32 > $O/r06_pmc_phase_stage.txt 2>&1
+bash $R/tools/pmc_phase.sh phase_window2_kernel 32 >> $O/r06_pmc_phase_stage.txt 2>&1
