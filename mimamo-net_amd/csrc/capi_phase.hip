@@ -15,6 +15,10 @@ int launch_phase_window(const float* coeff, const int32_t* ids, int64_t img_stri
 
 int64_t phase_frames_floats(int W, int64_t n);
 int launch_pyramid_frames(const mm_pyramid* h, const float* frames, int64_t n, float* f1, float* f2, hipStream_t stream);
+bool phase_window2_pair_applies(int out0_nhwc, int out1_nhwc);
+int launch_phase_window2_pair(const float* fr1, const float* fr2, const int32_t* ids, int64_t n, int64_t J, float* out0, int out0_nhwc,
+                              int out0_cstride, int out0_coffset, float* out1, int out1_nhwc, int out1_cstride, int out1_coffset,
+                              hipStream_t s);
 int launch_phase_window2(const float* fr, const int32_t* ids, int64_t n, int64_t J, int W, float* out, int out_nhwc, int out_cstride,
                          int out_coffset, hipStream_t s);
 
@@ -152,6 +156,13 @@ int mm_phase_diff_frames(mm_pyramid_t* h, const float* frames, int64_t n, const 
     // once per unique frame: pyramid, atan2 / magnitude, the frame-only blurs (B, R) -- one kernel; then one blur per (window, frame)
     int rc = mm::launch_pyramid_frames(h, frames, n, f1, f2, s);
     if (rc != MM_OK) return rc;
+    // both levels of a (window, band) in one workgroup (round 6) when the two outputs share a layout; else one launch per level
+    if (mm::phase_window2_pair_applies(out0_nhwc, out1_nhwc)) {
+        mm::prof_before(2, (double)J * 2 * 12 * (S * S + (S / 2) * (S / 2)) * 4, s, "phase_window2<48+24>");
+        rc = mm::launch_phase_window2_pair(f1, f2, ids, n, J, out0, out0_nhwc, out0_cstride, out0_coffset, out1, out1_nhwc, out1_cstride, out1_coffset, s);
+        mm::prof_after(2, s);
+        return rc;
+    }
     mm::prof_before(2, (double)J * 2 * 12 * (S * S) * 4, s, "phase_window2<48>");               // algorithmic write: 24 difference planes
     rc = mm::launch_phase_window2(f1, ids, n, J, (int)S, out0, out0_nhwc, out0_cstride, out0_coffset, s);
     mm::prof_after(2, s);

@@ -22,6 +22,9 @@
 #include "phase_math.h"
 #include "phase_blur.h"
 
+#ifndef MM_PW_ABLATE
+#define MM_PW_ABLATE 0           // measurement builds only (tools/): 1 no output stores, 2 no blur rounds, 4 every window reads window 0's frames
+#endif
 #ifndef MM_PW_CHUNK
 #define MM_PW_CHUNK 4   // frames whose plane loads the split kernel keeps in flight at once
 #endif
@@ -107,6 +110,19 @@ template <int W> struct PwIn {
     static constexpr int LEFT = PADDED ? PADX : 0;
     static constexpr int PLANE = PADDED ? (W - 1) * STRIDE + W + 2 * PADX : Cfg<W>::IN_PLANE;
 };
+// Workgroup barrier that orders LDS traffic only (the LDS queue drained, then s_barrier) -- hipcc's __syncthreads() puts s_waitcnt vmcnt(0) in front
+// of the barrier as well, i.e. waits for every global load AND STORE in flight.  Used for the blur loop and the store groups with
+// -DMM_PW_LDS_BARRIER=1: measured null (0.437 vs 0.441 ms, profiles/r06_ab_phase_window_barrier.txt), so the default stays __syncthreads().
+#ifndef MM_PW_LDS_BARRIER
+#define MM_PW_LDS_BARRIER 0
+#endif
+__device__ __forceinline__ void lds_barrier() {
+#if MM_PW_LDS_BARRIER
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#else
+    __syncthreads();
+#endif
+}
 template <int W> struct PwDense {
     static constexpr bool PADDED = false;
     static constexpr int STRIDE = W, LEFT = 0, PLANE = Cfg<W>::IN_PLANE;
@@ -135,10 +151,17 @@ __device__ __forceinline__ void row_pass_padded(const float* row_x0, float (&h)[
     }
 }
 
-template <int W, int F>
-__global__ void __launch_bounds__(Cfg<W>::NTHREADS)
-phase_window2_kernel(const float* __restrict__ fr, const int32_t* __restrict__ ids, int n_frames, float* __restrict__ out, int out_nhwc,
-                     int out_cstride, int out_coffset) {
+// Floats of LDS the body below uses for plane side W (its working planes + the per-wave partial sums); the agreed first-wrap frame is one more word.
+template <int W, int F> constexpr int pw2_lds_floats() { return F * (PwIn<W>::PLANE + Cfg<W>::TMP_PLANE) + 64 * (P - 1); }
+constexpr int pw2_store_groups(int W) { return W / (W == 48 ? 16 : 12); }
+
+// The body of phase_window2_kernel for a team of Cfg<W>::NTHREADS threads (tid = the thread's index in its team, lds = the team's region,
+// first_wrap_p = the word the workgroup agrees on).  PAIR: the team shares its workgroup with the team of the other level (phase_window2_kernel_pair
+// below): every team then executes the SAME number of barriers -- the blur rounds follow the shared first-wrap frame, and the level-2 team
+// adds the barriers of the level-1 team's third store group at the end.
+template <int W, int F, bool PAIR>
+__device__ __forceinline__ void pw2_body(const float* __restrict__ fr, const int32_t* __restrict__ ids, int n_frames, float* __restrict__ out,
+                                         int out_nhwc, int out_cstride, int out_coffset, float* lds, int* first_wrap_p, const int tid) {
     using C = Cfg<W>;
     constexpr int RPG = W == 48 ? 16 : 12;                    // rows per store group: RPG * W * 12 floats staged at a time
     constexpr int G = W / RPG;
@@ -150,12 +173,12 @@ phase_window2_kernel(const float* __restrict__ fr, const int32_t* __restrict__ i
 #endif
     constexpr int SLOTS = 3 * PX + MM_PW_STAGE_PAD;           // float4 slots per thread block in the store staging: 12 used + 1 pad
     static_assert(RPG * C::STRIPS * SLOTS * 4 <= WORK, "store staging fits the blur planes");
-    extern __shared__ __attribute__((aligned(16))) float lds[];      // WORK + 64 * (P - 1) floats + first_wrap
-    int& first_wrap = *reinterpret_cast<int*>(lds + WORK + 64 * (P - 1));
+    static_assert(WORK + 64 * (P - 1) == pw2_lds_floats<W, F>(), "the launchers size the region with this");
+    int& first_wrap = *first_wrap_p;
     float* in_x = lds;                              // [F][IN_PLANE]
     float* tmp_x = in_x + F * IN_PLANE_;            // [F][TMP_PLANE]
     float* red = lds + WORK;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lane = tid & 63, wave = tid >> 6;
     // consecutive windows share 12 of their 13 frames: keep them on one XCD (one L2) instead of spreading them over all eight
     const int logical = xcd_contiguous(blockIdx.x, gridDim.x);
     const int64_t j = logical >> 1;
@@ -187,7 +210,7 @@ phase_window2_kernel(const float* __restrict__ fr, const int32_t* __restrict__ i
     }
     int roff[(PX + 2 * PADX) / 4];                  // this thread's five row-pass chunks: loop constants
     row_chunk_offsets<W>(y, x0, roff);
-    if (tid == 0) first_wrap = P;
+    if (tid == 0 && (!PAIR || W == 48)) first_wrap = P;
     const float TWO_PI_F = 6.28318530717958647692f, PI_F = 3.14159265358979323846f;
     // ---- A
     const float* fo[P];
@@ -198,7 +221,7 @@ phase_window2_kernel(const float* __restrict__ fr, const int32_t* __restrict__ i
         unsigned run = 0;
 #pragma unroll
         for (int i = 0; i < P; ++i) {
-            const int id = min(max(ids[j * P + i], 0), n_frames - 1);    // memory-safe whatever the table holds (the shim range-checks it)
+            const int id = min(max(ids[(MM_PW_ABLATE & 4 ? 0 : j) * P + i], 0), n_frames - 1);    // memory-safe whatever the table holds (the shim range-checks it)
             fo[i] = fr + ((int64_t)id * 2 + band) * C::FRAME_FLOATS;
             float4 b4 = {0.f, 0.f, 0.f, 0.f}, p4 = {0.f, 0.f, 0.f, 0.f};
             if (active) {
@@ -234,7 +257,11 @@ phase_window2_kernel(const float* __restrict__ fr, const int32_t* __restrict__ i
 #endif
         __syncthreads();
     }
+#if MM_PW_ABLATE & 2
+    const int first = P;               // measurement build: no blur round
+#else
     const int first = first_wrap;
+#endif
     // ---- B
     float cprev[PX] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -253,7 +280,7 @@ phase_window2_kernel(const float* __restrict__ fr, const int32_t* __restrict__ i
                 float4{m4.x * (-TWO_PI_F * (float)(k & 255u)), m4.y * (-TWO_PI_F * (float)((k >> 8) & 255u)),
                        m4.z * (-TWO_PI_F * (float)((k >> 16) & 255u)), m4.w * (-TWO_PI_F * (float)(k >> 24))};
         }
-        __syncthreads();
+        lds_barrier();
         if (active) {
 #pragma unroll
             for (int f = 0; f < F; ++f) {
@@ -268,7 +295,7 @@ phase_window2_kernel(const float* __restrict__ fr, const int32_t* __restrict__ i
                 *reinterpret_cast<float4*>(tmp_x + f * C::TMP_PLANE + (y + R) * W + x0) = float4{h[0], h[1], h[2], h[3]};
             }
         }
-        __syncthreads();
+        lds_barrier();
         // (the next round's in_x stores are separated from this round's row-pass reads by the barrier above, its tmp_x stores from
         //  the column reads below by its own first barrier)
         if (active) {
@@ -355,14 +382,58 @@ phase_window2_kernel(const float* __restrict__ fr, const int32_t* __restrict__ i
                     mine[p * 3 + q] = v;
                 }
         }
-        __syncthreads();
+        lds_barrier();
         for (int idx = tid; idx < RPG * W * 3; idx += C::NTHREADS) {
             const int pix = idx / 3, part = idx - pix * 3;
             float* dst = out + ((j * W + g * RPG) * W + pix) * out_cstride + out_coffset + band * (P - 1) + part * 4;
+#if MM_PW_ABLATE & 1
+            if (stage[idx].x == 12345.678f)      // measurement build: no output stores (results wrong by construction)
+#endif
             *reinterpret_cast<float4*>(dst) = stage[idx + MM_PW_STAGE_PAD * (idx / (3 * PX))];      // skip the pad slot of every thread block
         }
-        if (g + 1 < G) __syncthreads();
+        if (g + 1 < G) lds_barrier();      // (the stores of this group stay in flight: their data left LDS with the reads above)
     }
+    if (PAIR) {   // the barriers of the store groups the OTHER team has and this one has not (level 1: three groups, level 2: two)
+        constexpr int G_MAX = pw2_store_groups(48);
+        static_assert(pw2_store_groups(48) >= pw2_store_groups(24), "level 1 has the most store groups");
+#pragma unroll
+        for (int g = G; g < G_MAX; ++g) {
+            lds_barrier();
+            lds_barrier();
+        }
+    }
+}
+
+template <int W, int F>
+__global__ void __launch_bounds__(Cfg<W>::NTHREADS)
+phase_window2_kernel(const float* __restrict__ fr, const int32_t* __restrict__ ids, int n_frames, float* __restrict__ out, int out_nhwc,
+                     int out_cstride, int out_coffset) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];      // pw2_lds_floats + first_wrap
+    pw2_body<W, F, false>(fr, ids, n_frames, out, out_nhwc, out_cstride, out_coffset, lds, reinterpret_cast<int*>(lds + pw2_lds_floats<W, F>()),
+                          (int)threadIdx.x);
+}
+
+// Round 6: BOTH levels of a (window, band) in one workgroup of twelve waves -- nine (level 1, 48 x 48) + three (level 2, 24 x 24).  The
+// level-1 kernel alone puts nine waves on a CU's four SIMDs (3 + 2 + 2 + 2: the waves of the two-wave SIMDs wait at every barrier for the
+// three-wave one; PMC: 54 % of the wave time at s_waitcnt / s_barrier) and its 97 KB of LDS keep every other workgroup off the CU; the level-2
+// kernel then runs as a launch of its own (0.098 of the 0.41 ms).  Three waves of level-2 work are exactly what the three lighter SIMDs
+// have room for: twelve waves, three per SIMD, the level-2 work inside the time the level-1 work takes anyway.  Each team runs the
+// unchanged arithmetic of its level in its own LDS region; they share the barriers (same count in both teams: see pw2_body) and the
+// first-wrap word -- a blur round one team would have skipped runs on an all-zero wrap count there and adds exact zeros.
+constexpr int PAIR_THREADS = Cfg<48>::NTHREADS + Cfg<24>::NTHREADS;
+static_assert(Cfg<48>::NTHREADS % 64 == 0 && PAIR_THREADS == 768, "whole waves per team; twelve waves");
+template <int F>
+__global__ void __launch_bounds__(PAIR_THREADS)
+phase_window2_kernel_pair(const float* __restrict__ fr1, const float* __restrict__ fr2, const int32_t* __restrict__ ids, int n_frames,
+                          float* __restrict__ out0, int out0_cstride, int out0_coffset, float* __restrict__ out1, int out1_cstride,
+                          int out1_coffset, int out_nhwc) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int L1 = pw2_lds_floats<48, F>(), L2 = pw2_lds_floats<24, F>();
+    static_assert(L1 % 4 == 0 && L2 % 4 == 0, "16-byte aligned regions");
+    int* first_wrap = reinterpret_cast<int*>(lds + L1 + L2);
+    const int tid = threadIdx.x;
+    if (tid < Cfg<48>::NTHREADS) pw2_body<48, F, true>(fr1, ids, n_frames, out0, out_nhwc, out0_cstride, out0_coffset, lds, first_wrap, tid);
+    else pw2_body<24, F, true>(fr2, ids, n_frames, out1, out_nhwc, out1_cstride, out1_coffset, lds + L1, first_wrap, tid - Cfg<48>::NTHREADS);
 }
 
 
@@ -644,7 +715,7 @@ template <int W, int F>
 static int launch_w2(const float* fr, const int32_t* ids, int n, int64_t J, float* out, int out_nhwc, int out_cstride, int out_coffset,
                      hipStream_t s) {
     using C = Cfg<W>;
-    const int lds_bytes = (F * (PwIn<W>::PLANE + C::TMP_PLANE) + 64 * (P - 1) + 4) * 4;
+    const int lds_bytes = (pw2_lds_floats<W, F>() + 4) * 4;
     MM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(phase_window2_kernel<W, F>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                lds_bytes));
     hipLaunchKernelGGL((phase_window2_kernel<W, F>), dim3((unsigned)(2 * J)), dim3(C::NTHREADS), lds_bytes, s, fr, ids, n, out, out_nhwc,
@@ -662,6 +733,28 @@ static int launch_w2s(const float* fr, const int32_t* ids, int n, int64_t J, flo
                                lds_bytes));
     hipLaunchKernelGGL((phase_window2s_kernel<W, F, 2>), dim3((unsigned)(4 * J)), dim3(C::NTHREADS), lds_bytes, s, fr, ids, n, out, out_nhwc,
                        out_cstride, out_coffset);
+    MM_LAUNCH_CHECK();
+    return MM_OK;
+}
+
+// Both levels in one launch (phase_window2_kernel_pair): opt-in, MM_PW_PAIR=1 (read per call: a test switches it), and only when the two
+// outputs share a layout (else the teams would not meet the same barriers) and MM_PW_SPLIT is not 2.  Measured: one launch fewer pays on small
+// batches (64 frames: 0.041 -> 0.028 ms, 192: 0.064 -> 0.052), is within +-2 % at 2 048 frames and 3 % SLOWER at 16 384
+// (profiles/r06_ab_phase_window_barrier.txt) -- the level-2 team's work does not hide in the level-1 kernel's idle SIMD slots.
+bool phase_window2_pair_applies(int out0_nhwc, int out1_nhwc) {
+    const char* e = getenv("MM_PW_PAIR");
+    const char* sp = getenv("MM_PW_SPLIT");
+    return e && atoi(e) == 1 && !(sp && atoi(sp) == 2) && (out0_nhwc != 0) == (out1_nhwc != 0);
+}
+int launch_phase_window2_pair(const float* fr1, const float* fr2, const int32_t* ids, int64_t n, int64_t J, float* out0, int out0_nhwc,
+                              int out0_cstride, int out0_coffset, float* out1, int out1_nhwc, int out1_cstride, int out1_coffset,
+                              hipStream_t s) {
+    if (J <= 0) return MM_OK;
+    constexpr int F = 3;
+    const int lds_bytes = (pw2_lds_floats<48, F>() + pw2_lds_floats<24, F>() + 4) * 4;
+    MM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(phase_window2_kernel_pair<F>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
+    hipLaunchKernelGGL((phase_window2_kernel_pair<F>), dim3((unsigned)(2 * J)), dim3(PAIR_THREADS), lds_bytes, s, fr1, fr2, ids, (int)n, out0,
+                       out0_cstride, out0_coffset, out1, out1_cstride, out1_coffset, out0_nhwc);
     MM_LAUNCH_CHECK();
     return MM_OK;
 }

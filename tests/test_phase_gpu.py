@@ -199,6 +199,41 @@ def test_wave_per_frame_kernel_reproduces_the_three_wave_kernel_bit_for_bit(pde,
             assert torch.equal(a.view(torch.int32), b.view(torch.int32)), (n, mode, k, (a - b).abs().max().item(), int((a != b).sum()))
 
 
+def test_pair_window_kernel_equals_one_launch_per_level(pde, dev, monkeypatch):
+    """Round 6, built and measured near-null (profiles/r06_ab_phase_window_barrier.txt), opt-in as MM_PW_PAIR=1: phase_window2_kernel_pair runs both
+    levels of a (window, band) in ONE workgroup of twelve waves (nine of level 1 + three of level 2, three per SIMD), each team with the unchanged
+    arithmetic of its level in its own LDS region, sharing the barriers and the first-wrap frame (a blur round one team alone would have
+    skipped runs on an all-zero wrap count and adds exact zeros).  Values equal to one launch per level in both layouts, on wrapping clips,
+    arbitrary id patterns and a still clip (no blur round at all)."""
+    n = 3 * 64
+    base = np.concatenate([synthetic.textured_gray(64, 48, seed=700 + c) for c in range(3)])
+    fast = np.stack([np.roll(base[3 * (t // 64)], (t % 64), axis=1) for t in range(n)]).astype(np.float32)
+    frames = torch.from_numpy(np.ascontiguousarray(fast)).to(dev)
+    one = torch.clamp(torch.arange(64, device=dev)[:, None] + torch.arange(-6, 7, device=dev)[None, :], 0, 63)
+    ids = (one[None] + 64 * torch.arange(3, device=dev)[:, None, None]).reshape(n, 13).int().contiguous()
+    rng = np.random.RandomState(12)
+    odd = torch.from_numpy(np.stack([np.arange(13) * 5 + 2, np.arange(13)[::-1] + 90, rng.randint(0, n, 13), rng.randint(0, n, 13)]).astype(np.int32)).to(dev)
+    still = frames[:1].repeat(16, 1, 1).contiguous()
+    slow = torch.from_numpy(synthetic.textured_gray(64, 48, seed=78)).to(dev)
+    cases = ((frames, ids), (frames, odd), (still, ids[:16].clamp(max=15).contiguous()), (slow, ids[:64].contiguous()))
+
+    def run():
+        out = []
+        for f, i in cases:
+            out += [t.clone() for t in pde.phase_diff_frames(f, i)]
+            a0, a1 = pde.phase_diff_frames(f, i, nhwc=True, out1_cstride=88, out1_coffset=64)
+            out += [a0.clone(), a1[..., 64:].clone()]
+        return out
+    monkeypatch.delenv("MM_PW_PAIR", raising=False)
+    per_level = run()
+    monkeypatch.setenv("MM_PW_PAIR", "1")
+    pair = run()
+    monkeypatch.delenv("MM_PW_PAIR")
+    for k, (a, b) in enumerate(zip(per_level, pair)):
+        assert a.shape == b.shape and torch.isfinite(b).all() and torch.equal(a, b), (k, (a - b).abs().max().item())
+    assert per_level[8].abs().max() == 0 and pair[8].abs().max() == 0            # still clip: identically zero
+
+
 def test_time_split_window_kernel_equals_the_one_workgroup_form(pde, dev, monkeypatch):
     """Round 6 (verdict item 3b), built and measured SLOWER (profiles/r06_ab_phase_window_split.txt), kept opt-in as MM_PW_SPLIT=2:
     phase_window2s_kernel runs TWO workgroups per (window, band), each owning six of the twelve difference planes (split along time: the
