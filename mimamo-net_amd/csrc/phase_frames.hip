@@ -25,6 +25,9 @@
 #ifndef MM_PW_ABLATE
 #define MM_PW_ABLATE 0           // measurement builds only (tools/): 1 no output stores, 2 no blur rounds, 4 every window reads window 0's frames
 #endif
+#ifndef MM_PW_SPLIT_F
+#define MM_PW_SPLIT_F 2         // frames per barrier round of the time-split kernel: two padded planes = 65 KB of LDS, two workgroups per CU
+#endif
 #ifndef MM_PW_CHUNK
 #define MM_PW_CHUNK 4   // frames whose plane loads the split kernel keeps in flight at once
 #endif
@@ -464,7 +467,9 @@ __device__ __forceinline__ void phase_window2s_body(const float* __restrict__ fr
     static_assert(KN * NH == P - 1 && PPX * EW == KN, "the difference planes split evenly");
     constexpr int RPG = W == 48 ? (NH == 1 ? 16 : 24) : (NH == 1 ? 12 : 24);   // rows per store group
     constexpr int G = W / RPG;
-    constexpr int WORK = F * (C::IN_PLANE + C::TMP_PLANE);
+    using PW = PwIn<W>;                                       // padded row-pass planes, as in the one-workgroup kernel
+    constexpr int IN_PLANE_ = PW::PLANE;
+    constexpr int WORK = F * (IN_PLANE_ + C::TMP_PLANE);
 #ifndef MM_PW_STAGE_PAD
 #define MM_PW_STAGE_PAD 1                                     // 0: the round-4 staging (12-slot thread blocks), for the A/B
 #endif
@@ -472,13 +477,14 @@ __device__ __forceinline__ void phase_window2s_body(const float* __restrict__ fr
     static_assert(RPG * C::STRIPS * SLOTS * EW <= WORK, "store staging fits the blur planes");
     int& first_wrap = *reinterpret_cast<int*>(lds + WORK + 64 * (P - 1));
     float* in_x = lds;                              // [F][IN_PLANE]
-    float* tmp_x = in_x + F * C::IN_PLANE;          // [F][TMP_PLANE]
+    float* tmp_x = in_x + F * IN_PLANE_;            // [F][TMP_PLANE]
     float* red = lds + WORK;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const bool active = tid < C::ACTIVE;
     const int y = active ? tid / C::STRIPS : 0;
     const int x0 = active ? (tid - y * C::STRIPS) * PX : 0;
     const int px = y * W + x0;
+    const int ipx = y * PW::STRIDE + PW::LEFT + x0;
     // the zero rows above / below each tmp_x plane (column-pass halo; everything else is written before it is read -- round 6: the whole 61 KB
     // region used to be cleared, 27 ds_write_b32 per thread)
 #ifndef MM_PW_CLEAR_ALL
@@ -491,7 +497,13 @@ __device__ __forceinline__ void phase_window2s_body(const float* __restrict__ fr
             const int f = i / (2 * R * W), r = i - f * (2 * R * W);
             tmp_x[f * C::TMP_PLANE + (r < R * W ? r : (W + R) * W + (r - R * W))] = 0.f;
         }
-        if (tid < F * 2 * PADX) in_x[(tid / (2 * PADX)) * C::IN_PLANE + W * W + tid % (2 * PADX)] = 0.f;   // the slack row_pass_pre reads as zero padding
+        if (!PW::PADDED && tid < F * 2 * PADX) in_x[(tid / (2 * PADX)) * IN_PLANE_ + W * W + tid % (2 * PADX)] = 0.f;   // the slack row_pass_pre reads as zero padding
+        if (PW::PADDED) {
+            for (int i = tid; i < F * W * 4; i += C::NTHREADS) {
+                const int f = i / (W * 4), r = (i >> 2) % W, q = i & 3;
+                *reinterpret_cast<float4*>(in_x + f * IN_PLANE_ + r * PW::STRIDE + (q < 2 ? 4 * q : W + PADX + 4 * (q - 2))) = float4{0.f, 0.f, 0.f, 0.f};
+            }
+        }
     }
     int roff[(PX + 2 * PADX) / 4];                  // this thread's five row-pass chunks: loop constants
     row_chunk_offsets<W>(y, x0, roff);
@@ -579,7 +591,7 @@ __device__ __forceinline__ void phase_window2s_body(const float* __restrict__ fr
             //  the magnitude; the split form only before the column pass -- 12 registers less across the two barriers of a round)
             if (NH == 1) r4[f] = *reinterpret_cast<const float4*>(fo[i] + 2 * C::PLANE + px);
             const unsigned msk = (2u << i) - 1u;
-            *reinterpret_cast<float4*>(in_x + f * C::IN_PLANE + px) =
+            *reinterpret_cast<float4*>(in_x + f * IN_PLANE_ + ipx) =
                 float4{m4.x * (-TWO_PI_F * (float)__builtin_popcount(wb[0] & msk)), m4.y * (-TWO_PI_F * (float)__builtin_popcount(wb[1] & msk)),
                        m4.z * (-TWO_PI_F * (float)__builtin_popcount(wb[2] & msk)), m4.w * (-TWO_PI_F * (float)__builtin_popcount(wb[3] & msk))};
         }
@@ -590,9 +602,10 @@ __device__ __forceinline__ void phase_window2s_body(const float* __restrict__ fr
                 if (base + f > K0 + KN) continue;
                 float h[PX];
 #if MM_PW_ROW_PRE
-                row_pass_pre<W>(in_x + f * C::IN_PLANE, roff, h);
+                row_pass_pre<W>(in_x + f * IN_PLANE_, roff, h);
 #else
-                row_pass<W>(in_x + f * C::IN_PLANE, y, x0, h);
+                if (PW::PADDED) row_pass_padded<W>(in_x + f * IN_PLANE_ + y * PW::STRIDE + x0, h);
+                else row_pass<W>(in_x + f * IN_PLANE_, y, x0, h);
 #endif
                 *reinterpret_cast<float4*>(tmp_x + f * C::TMP_PLANE + (y + R) * W + x0) = float4{h[0], h[1], h[2], h[3]};
                 if (NH != 1) __builtin_amdgcn_sched_barrier(0);       // one frame's 20-float row window at a time (registers)
@@ -728,7 +741,7 @@ template <int W, int F>
 static int launch_w2s(const float* fr, const int32_t* ids, int n, int64_t J, float* out, int out_nhwc, int out_cstride, int out_coffset,
                       hipStream_t s) {
     using C = Cfg<W>;
-    const int lds_bytes = (F * (C::IN_PLANE + C::TMP_PLANE) + 64 * (P - 1) + 4) * 4;
+    const int lds_bytes = (F * (PwIn<W>::PLANE + C::TMP_PLANE) + 64 * (P - 1) + 4) * 4;
     MM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(phase_window2s_kernel<W, F, 2>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                lds_bytes));
     hipLaunchKernelGGL((phase_window2s_kernel<W, F, 2>), dim3((unsigned)(4 * J)), dim3(C::NTHREADS), lds_bytes, s, fr, ids, n, out, out_nhwc,
@@ -766,8 +779,8 @@ int launch_phase_window2(const float* fr, const int32_t* ids, int64_t n, int64_t
     // MM_PW_SPLIT=2 (read per call: a test switches it): the time-split form above -- measured slower, default off
     const char* e = getenv("MM_PW_SPLIT");
     if (e && atoi(e) == 2) {
-        if (W == 48) return launch_w2s<48, 3>(fr, ids, (int)n, J, out, out_nhwc, out_cstride, out_coffset, s);
-        if (W == 24) return launch_w2s<24, 3>(fr, ids, (int)n, J, out, out_nhwc, out_cstride, out_coffset, s);
+        if (W == 48) return launch_w2s<48, MM_PW_SPLIT_F>(fr, ids, (int)n, J, out, out_nhwc, out_cstride, out_coffset, s);
+        if (W == 24) return launch_w2s<24, MM_PW_SPLIT_F>(fr, ids, (int)n, J, out, out_nhwc, out_cstride, out_coffset, s);
         return MM_ERR_UNSUPPORTED;
     }
     // F = 3 frames per barrier round; 4 / 5 / 7 measured equal or slower (0.547 / 0.554 / 0.554 / 0.593 ms per 2 048 windows):
