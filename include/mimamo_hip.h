@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define MM_VERSION 105 /* 0.1.5: round 5 removes the CU-mask stream entry points of 0.1.4 (measured null, never used by the product path) */
+#define MM_VERSION 106 /* 0.1.6: round 6 adds mm_pyramid_host_tables (host-only, for tests); 0.1.5 removed the CU-mask stream entry points of 0.1.4 */
 
 typedef enum mm_status {
     MM_OK = 0,
@@ -71,6 +71,13 @@ int mm_pyramid_destroy(mm_pyramid_t* h);
  * `out` must hold side*side doubles.  Also returns the crop bounds used going INTO that level
  * (level 1: {0, 2*size}) in crop[0..1]. */
 int mm_pyramid_host_mask(int size, int height, int nbands, int level, int band, double* out, int* crop);
+
+/* Host-side, for testing (no GPU needed): the packed fp32 constant tables a handle of this configuration uploads -- the DCT and twiddle
+ * tables, the four complex band masks in the kernels' half-plane layout and the same masks once more in MFMA-fragment order for
+ * pyramid_wave_kernel (csrc/pyramid_tables.h gives the offsets).  Returns the number of floats; writes them when out != NULL and
+ * capacity is large enough (MM_ERR_WORKSPACE otherwise).  Negative: an MM_ERR_* status (unsupported configuration, or a table that
+ * violates an assumption a kernel relies on, e.g. the spectrum blocks pyramid_wave_kernel skips as exactly zero). */
+int64_t mm_pyramid_host_tables(int size, int height, int nbands, int scale_factor, float* out, int64_t capacity);
 
 /* frames: device f32 [n, size, size].  For every image and band writes the kept quadrant of the
  * level-1 and level-2 complex band coefficients (interleaved re,im):

@@ -27,6 +27,7 @@ SIGNATURES = {
     "mm_pyramid_create": (_i, [_c.POINTER(_vp), _i, _i, _i, _i]),
     "mm_pyramid_destroy": (_i, [_vp]),
     "mm_pyramid_host_mask": (_i, [_i, _i, _i, _i, _i, _c.POINTER(_c.c_double), _c.POINTER(_i)]),
+    "mm_pyramid_host_tables": (_i64, [_i, _i, _i, _i, _c.POINTER(_f), _i64]),
     "mm_pyramid_build": (_i, [_vp, _vp, _i64, _vp, _i64, _i64, _vp, _i64, _i64, _vp]),
     "mm_pyramid_build_batch": (_i, [_vp, _vp, _i64, _i64, _vp, _vp, _vp]),
     "mm_phase_extract": (_i, [_vp, _vp, _vp, _i64, _i64, _i64, _i, _i, _vp, _i, _i, _i, _vp]),

@@ -64,6 +64,21 @@ int mm_pyramid_host_mask(int size, int height, int nbands, int level, int band, 
     return MM_OK;
 }
 
+int64_t mm_pyramid_host_tables(int size, int height, int nbands, int scale_factor, float* out, int64_t capacity) {
+    int rc = mm::check_config(size, height, nbands, scale_factor);
+    if (rc != MM_OK) return rc;
+    mm::PyramidTables t;
+    rc = mm::build_pyramid_tables(mm::PyramidConfig{size, height, nbands, scale_factor}, t);
+    std::vector<float> packed;
+    if (rc == MM_OK) rc = mm::pack_pyramid_tables(t, packed);
+    if (rc != MM_OK) return rc;
+    if (out) {
+        if (capacity < (int64_t)packed.size()) return MM_ERR_WORKSPACE;
+        std::copy(packed.begin(), packed.end(), out);
+    }
+    return (int64_t)packed.size();
+}
+
 int mm_pyramid_create(mm_pyramid_t** out, int size, int height, int nbands, int scale_factor) {
     if (!out) return MM_ERR_INVALID_ARG;
     *out = nullptr;

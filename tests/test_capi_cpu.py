@@ -26,7 +26,7 @@ def test_exports_match_header(L):
     assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
     for name in declared:
         assert hasattr(L, name), name
-    assert L.mm_version() == 105
+    assert L.mm_version() == 106
     assert b"too small" in L.mm_status_string(-2)
 
 
@@ -49,6 +49,48 @@ def test_host_masks_match_reference(L, golden):
         ref = g["lo0"][s:e, s:e] * g["lomask_0"] * g["himask_1"] * g["anglemask_1_%d" % b]
         np.testing.assert_allclose(m, ref, rtol=0, atol=2e-15)
         assert crop == [s, e] == [24, 72]  # integer crop bounds: bit-exact
+
+
+def test_fragment_ordered_masks_are_a_relayout_of_the_plain_ones(L):
+    """Round 6: pyramid_wave_kernel (csrc/pyramid_wave.hip) reads the four band masks in MFMA-fragment order -- the complex value lane
+    (li, lk) multiplies into its A fragment of k-step ks of 16-row tile tr sits at [(tr * KS + ks) * 64 + lane], row 16 tr + frag_row(li),
+    column 4 ks + lk, band 1 read transposed -- and skips the last three k-steps of the first and the last level-1 tile row as exactly
+    zero.  Both are properties of the packed host tables (mm_pyramid_host_tables, no GPU): the fragment tables are a pure re-layout of the
+    plain tables the round-3 kernels read, and the skipped blocks are zero."""
+    n = L.mm_pyramid_host_tables(48, 4, 2, 2, None, 0)
+    assert n > 0
+    buf = (ctypes.c_float * n)()
+    assert L.mm_pyramid_host_tables(48, 4, 2, 2, buf, n) == n
+    assert L.mm_pyramid_host_tables(48, 4, 2, 2, buf, n - 1) == -6                      # MM_ERR_WORKSPACE
+    assert L.mm_pyramid_host_tables(48, 4, 4, 2, None, 0) == -3                         # unsupported configuration
+    t = np.frombuffer(buf, dtype=np.float32)
+    S = 48
+    off = {"dct": 0, "ec": S * S, "es": 2 * S * S, "m1b0": 3 * S * S}                   # csrc/pyramid_tables.h
+    off["m1b1"] = off["m1b0"] + 96 * 48 * 2
+    off["m2b0"] = off["m1b1"] + 96 * 48 * 2
+    off["m2b1"] = off["m2b0"] + 48 * 24 * 2
+    off["f1b0"] = off["m2b1"] + 48 * 24 * 2
+    off["f1b1"] = off["f1b0"] + 96 * 48 * 2
+    off["f2b0"] = off["f1b1"] + 96 * 48 * 2
+    off["f2b1"] = off["f2b0"] + 48 * 24 * 2
+    assert n == off["f2b1"] + 48 * 24 * 2
+    frag_row = lambda li: 4 * (li & 3) + (li >> 2)
+    assert sorted(frag_row(li) for li in range(16)) == list(range(16))
+    for level, H in ((1, 48), (2, 24)):
+        KS, NTR = H // 4, 2 * H // 16
+        for band in (0, 1):
+            plain = t[off["m%db%d" % (level, band)]:][:2 * H * H * 2].reshape((2 * H, H, 2) if band == 0 else (H, 2 * H, 2))
+            frag = t[off["f%db%d" % (level, band)]:][:2 * H * H * 2].reshape(NTR, KS, 64, 2)
+            assert np.abs(plain).max() > 0
+            for tr in range(NTR):
+                for ks in range(KS):
+                    for lane in range(64):
+                        row, col = 16 * tr + frag_row(lane & 15), 4 * ks + (lane >> 4)
+                        want = plain[row, col] if band == 0 else plain[col, row]
+                        assert (frag[tr, ks, lane] == want).all(), (level, band, tr, ks, lane)
+            if level == 1:      # EDGE_ZERO_KSTEPS = 3: the spectrum beyond radius 48
+                assert np.abs(frag[0, KS - 3:]).max() == 0.0 and np.abs(frag[NTR - 1, KS - 3:]).max() == 0.0
+                assert np.abs(frag[0, :KS - 3]).max() > 0.0 and np.abs(frag[1, KS - 3:]).max() > 0.0
 
 
 def test_half_plane_support_is_exact(golden):
