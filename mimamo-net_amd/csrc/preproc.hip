@@ -13,6 +13,7 @@
 #include <cmath>
 #include <new>
 #include <vector>
+#include <cstdlib>
 #include "mm_common.h"
 
 namespace mm {
@@ -122,6 +123,67 @@ preproc_gray_kernel(const uint8_t* __restrict__ frames, int S, int G, int ksize,
     }
 }
 
+// ---- gray, fast form (round 6).  The kernel above spends its time in the LDS pipe: byte-wide LDS accesses cost ~26 LDS cycles per wave
+// instruction on this chip (PMC: SQ_LDS_IDX_ACTIVE / SQ_INSTS_LDS; a ds_read_b32 costs 2), and with the 15 taps of the Lanczos filter
+// (112 -> 48) it issues thirty accesses per output: 0.173 ms per 2 048 frames, LDS 73 % busy.  Here every LDS access is a word or wider: the
+// source arrives as 32-bit words (four pixels = three words), the L plane stays bytes but is read as five words + four funnel shifts per
+// output, the horizontal-pass image is kept as ints, and the tables (bounds, weights padded to sixteen per position: the builder zero-fills
+// beyond a position's taps, so all sixteen are applied unconditionally) sit in LDS.  Same integer arithmetic on the same values: bit-exact
+// with PIL like the kernel above (tests/test_preproc.py).  Needs ksize <= 16, S * S % 4 == 0 and 4-byte aligned frames; the launcher falls
+// back to the kernel above otherwise.
+constexpr int GRAY_KW = 16;
+__device__ __forceinline__ int dot4(unsigned bytes, const int4 k) {
+    return (int)(bytes & 255u) * k.x + (int)((bytes >> 8) & 255u) * k.y + (int)((bytes >> 16) & 255u) * k.z + (int)(bytes >> 24) * k.w;
+}
+__global__ void __launch_bounds__(256)
+preproc_gray_words_kernel(const uint8_t* __restrict__ frames, int S, int G, int ksize, const int* __restrict__ bounds,
+                          const int* __restrict__ kk, float* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned* L4 = reinterpret_cast<unsigned*>(smem);                       // [S*S / 4 + 8] bytes of L, as words (+ slack for the last taps)
+    int* T = reinterpret_cast<int*>(smem) + ((S * S / 4 + 8 + 3) & ~3);     // [S*G] ints
+    int* s_kk = T + ((S * G + 3) & ~3);                                     // [G][16]
+    int* s_bounds = s_kk + GRAY_KW * G;                                     // [G][2]
+    const int64_t n = blockIdx.x;
+    const unsigned* w = reinterpret_cast<const unsigned*>(frames + n * (int64_t)S * S * 3);
+    const int tid = threadIdx.x;
+    for (int i = tid; i < 2 * G; i += 256) s_bounds[i] = bounds[i];
+    for (int i = tid; i < GRAY_KW * G; i += 256) s_kk[i] = (i & (GRAY_KW - 1)) < ksize ? kk[(i / GRAY_KW) * ksize + (i & (GRAY_KW - 1))] : 0;
+    if (tid < 8) L4[S * S / 4 + tid] = 0u;
+    // convert('L'): (19595 R + 38470 G + 7471 B + 0x8000) >> 16, four pixels per step
+    for (int q = tid; q < S * S / 4; q += 256) {
+        const unsigned w0 = w[3 * q], w1 = w[3 * q + 1], w2 = w[3 * q + 2];
+        const unsigned l0 = (19595u * (w0 & 255u) + 38470u * ((w0 >> 8) & 255u) + 7471u * ((w0 >> 16) & 255u) + 0x8000u) >> 16;
+        const unsigned l1 = (19595u * (w0 >> 24) + 38470u * (w1 & 255u) + 7471u * ((w1 >> 8) & 255u) + 0x8000u) >> 16;
+        const unsigned l2 = (19595u * ((w1 >> 16) & 255u) + 38470u * (w1 >> 24) + 7471u * (w2 & 255u) + 0x8000u) >> 16;
+        const unsigned l3 = (19595u * ((w2 >> 8) & 255u) + 38470u * ((w2 >> 16) & 255u) + 7471u * (w2 >> 24) + 0x8000u) >> 16;
+        L4[q] = (l0 & 255u) | ((l1 & 255u) << 8) | ((l2 & 255u) << 16) | (l3 << 24);
+    }
+    __syncthreads();
+    for (int i = tid; i < S * G; i += 256) {  // horizontal pass: sixteen bytes from byte offset o of L
+        const int y = i / G, xx = i - y * G;
+        const int o = y * S + s_bounds[xx * 2];
+        const unsigned* p = L4 + (o >> 2);
+        const unsigned a0 = p[0], a1 = p[1], a2 = p[2], a3 = p[3], a4 = p[4];
+        const unsigned sh = (unsigned)(o & 3) * 8u;
+        const int4* k4 = reinterpret_cast<const int4*>(s_kk + xx * GRAY_KW);
+        int acc = 1 << (PRECISION_BITS - 1);
+        acc += dot4(__builtin_amdgcn_alignbit(a1, a0, sh), k4[0]);
+        acc += dot4(__builtin_amdgcn_alignbit(a2, a1, sh), k4[1]);
+        acc += dot4(__builtin_amdgcn_alignbit(a3, a2, sh), k4[2]);
+        acc += dot4(__builtin_amdgcn_alignbit(a4, a3, sh), k4[3]);
+        T[i] = clip8(acc);
+    }
+    __syncthreads();
+    for (int i = tid; i < G * G; i += 256) {  // vertical pass + /255
+        const int yy = i / G, xx = i - yy * G;
+        const int ymin = s_bounds[yy * 2], cnt = s_bounds[yy * 2 + 1];
+        const int* k = s_kk + yy * GRAY_KW;
+        int acc = 1 << (PRECISION_BITS - 1);
+        for (int y = 0; y < cnt; ++y) acc += T[(ymin + y) * G + xx] * k[y];
+        out[n * (int64_t)G * G + i] = __fdiv_rn((float)clip8(acc), 255.0f);
+    }
+}
+
 // ---- rgb, zero-bordered packed NHWC3 output (the stem's fastest input): one workgroup per (frame, 16 output rows).
 // The general kernel below evaluates the horizontal pass once per (output row, vertical tap): 16 rows x 2 taps = 32 evaluations per
 // output column for the 8-10 input rows a block really touches.  Here the block's input rows go through the horizontal pass ONCE
@@ -216,6 +278,101 @@ preproc_rgb3_kernel(const uint8_t* __restrict__ frames, int S, int R, int C, int
             const int cnt = s_cnt[ry];
             for (int y = 0; y < cnt; ++y) acc += (int)hp[y * RF] * s_k[ry][y];
             img[((int64_t)(row0 + ry + 3) * CP + 3) * 3 + fl] = lut[clip8(acc)];
+        }
+    }
+}
+
+// ---- rgb3, word-wide LDS form (round 6).  preproc_rgb3_kernel above is LDS-bound on byte accesses (PMC: 3.8e7 LDS instructions at 5.3 LDS
+// cycles each, the LDS pipe 68 % busy over its 0.49 ms; a byte-wide access costs ~26 cycles, a ds_read_b32 two): twelve byte reads + three
+// byte writes per (input row, column) in the horizontal pass, a byte read per tap and float in the vertical one.  Here the horizontal pass
+// reads the twelve source bytes of its four taps as four words + three funnel shifts and writes its three channel bytes as ONE packed word;
+// the vertical pass is a lane per pixel (one word per tap for the three channels) and stores the pixel's three floats together.  Same
+// integer arithmetic on the same values, same look-up table: bit-exact with PIL like the kernel above.  Needs C <= 256, S * 3 % 4 == 0 and
+// 4-byte aligned frames (the launcher checks, and falls back).
+__global__ void __launch_bounds__(256)
+preproc_rgb3_words_kernel(const uint8_t* __restrict__ frames, int S, int R, int C, int ksize, const int* __restrict__ bounds,
+                          const int* __restrict__ kk, float mean0, float mean1, float mean2, float* __restrict__ out, int max_in) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char hrow[];
+    unsigned* hw = reinterpret_cast<unsigned*>(hrow);                         // [max_in][C] packed (c0 | c1 << 8 | c2 << 16)
+    unsigned* srow = hw + (((max_in * C) + 3) & ~3);                          // [n_in][S * 3 / 4] source rows as words (+ 4 words of slack)
+    const int64_t n = blockIdx.x;
+    const int row0 = blockIdx.y * RGB_ROWS;
+    const int off = (int)rintf((R - C) / 2.0f);  // CenterCrop: int(round((256-224)/2.)) = 16
+    const uint8_t* src = frames + n * (int64_t)S * S * 3;
+    const int CP = C + 6;
+    float* img = out + n * (int64_t)CP * CP * 3;
+    const int rows = min(RGB_ROWS, C - row0);
+    for (int i = threadIdx.x; i < rows * 18; i += 256) {      // the 3-pixel zero border of this block's rows
+        const int ry = i / 18, e = i - ry * 18;
+        img[((int64_t)(row0 + ry + 3) * CP + (e < 9 ? 0 : C + 3)) * 3 + (e < 9 ? e : e - 9)] = 0.f;
+    }
+    if (blockIdx.y == 0)
+        for (int i = threadIdx.x; i < 3 * CP * 3; i += 256) img[i] = 0.f;
+    if (blockIdx.y == gridDim.y - 1)
+        for (int i = threadIdx.x; i < 3 * CP * 3; i += 256) img[(int64_t)(C + 3) * CP * 3 + i] = 0.f;
+    const int yy_first = row0 + off, yy_last = row0 + rows - 1 + off;
+    const int in_lo = bounds[yy_first * 2];
+    const int n_in = bounds[yy_last * 2] + bounds[yy_last * 2 + 1] - in_lo;
+    const int SW = S * 3 / 4;                                 // words per source row
+    {
+        const unsigned* s0 = reinterpret_cast<const unsigned*>(src + (int64_t)in_lo * S * 3);
+        for (int i = threadIdx.x; i < n_in * SW; i += 256) srow[i] = s0[i];
+        if (threadIdx.x < 4) srow[n_in * SW + threadIdx.x] = 0u;
+    }
+    __shared__ int s_rel[RGB_ROWS], s_cnt[RGB_ROWS], s_k[RGB_ROWS][4];
+    __shared__ float s_lut[3][256];
+    if (threadIdx.x < rows) {
+        const int yy = row0 + threadIdx.x + off;
+        s_rel[threadIdx.x] = bounds[yy * 2] - in_lo;
+        s_cnt[threadIdx.x] = bounds[yy * 2 + 1];
+        for (int y = 0; y < 4; ++y) s_k[threadIdx.x][y] = y < ksize ? kk[yy * ksize + y] : 0;
+    }
+    for (int i = threadIdx.x; i < 768; i += 256) {
+#pragma clang fp contract(off)
+        const int c = i >> 8;
+        const float q = (float)(i & 255) / 255.0f;
+        const float m255 = q * 255.0f;
+        s_lut[c][i & 255] = m255 - (c == 0 ? mean0 : c == 1 ? mean1 : mean2);
+    }
+    __syncthreads();
+    const int cx = threadIdx.x;
+    if (cx < C) {     // horizontal pass, once per (input row, cropped output column): taps beyond a position's count carry zero weights
+        const int xx = cx + off;
+        const int xmin = bounds[xx * 2];
+        int kx[4];
+#pragma unroll
+        for (int x = 0; x < 4; ++x) kx[x] = x < ksize ? kk[xx * ksize + x] : 0;
+        for (int r = 0; r < n_in; ++r) {
+            const int bo = (r * S + xmin) * 3;
+            const unsigned* p = srow + (bo >> 2);
+            const unsigned a0 = p[0], a1 = p[1], a2 = p[2], a3 = p[3];
+            const unsigned sh = (unsigned)(bo & 3) * 8u;
+            const unsigned b0 = __builtin_amdgcn_alignbit(a1, a0, sh), b1 = __builtin_amdgcn_alignbit(a2, a1, sh),
+                           b2 = __builtin_amdgcn_alignbit(a3, a2, sh);
+            const int rnd = 1 << (PRECISION_BITS - 1);
+            const int c0 = rnd + (int)(b0 & 255u) * kx[0] + (int)(b0 >> 24) * kx[1] + (int)((b1 >> 16) & 255u) * kx[2] + (int)((b2 >> 8) & 255u) * kx[3];
+            const int c1 = rnd + (int)((b0 >> 8) & 255u) * kx[0] + (int)(b1 & 255u) * kx[1] + (int)(b1 >> 24) * kx[2] + (int)((b2 >> 16) & 255u) * kx[3];
+            const int c2 = rnd + (int)((b0 >> 16) & 255u) * kx[0] + (int)((b1 >> 8) & 255u) * kx[1] + (int)(b2 & 255u) * kx[2] + (int)(b2 >> 24) * kx[3];
+            hw[r * C + cx] = (unsigned)clip8(c0) | ((unsigned)clip8(c1) << 8) | ((unsigned)clip8(c2) << 16);
+        }
+    }
+    __syncthreads();
+    if (cx < C) {     // vertical pass: a lane owns a pixel column, three floats per store
+        for (int ry = 0; ry < rows; ++ry) {
+            const unsigned* hp = hw + s_rel[ry] * C + cx;
+            const int cnt = s_cnt[ry];
+            int c0 = 1 << (PRECISION_BITS - 1), c1 = c0, c2 = c0;
+            for (int y = 0; y < cnt; ++y) {
+                const unsigned v = hp[y * C];
+                const int k = s_k[ry][y];
+                c0 += (int)(v & 255u) * k;
+                c1 += (int)((v >> 8) & 255u) * k;
+                c2 += (int)((v >> 16) & 255u) * k;
+            }
+            float* dst = img + ((int64_t)(row0 + ry + 3) * CP + 3 + cx) * 3;
+            dst[0] = s_lut[0][clip8(c0)];
+            dst[1] = s_lut[1][clip8(c1)];
+            dst[2] = s_lut[2][clip8(c2)];
         }
     }
 }
@@ -383,11 +540,20 @@ int mm_preproc_forward(mm_preproc_t* h, const uint8_t* frames, int64_t n, float*
     MM_CHECK_DEVICE(h);
     hipStream_t s = (hipStream_t)stream_;
     if (gray_out) {
-        const int lds = h->in_size * h->in_size + h->in_size * h->gray_size;
+        const int S = h->in_size, G = h->gray_size;
+        // word-wide LDS form when it applies (MM_PREPROC_WORDS=0: the byte form, for the A/B; read once)
+        static const bool words_on = !(getenv("MM_PREPROC_WORDS") && atoi(getenv("MM_PREPROC_WORDS")) == 0);
+        const int lds_w = (((S * S / 4 + 8 + 3) & ~3) + ((S * G + 3) & ~3) + (mm::GRAY_KW + 2) * G) * 4;
+        const bool words = words_on && h->lan.ksize <= mm::GRAY_KW && (S * S) % 4 == 0 && (reinterpret_cast<uintptr_t>(frames) & 3) == 0 && lds_w <= 64 * 1024;
+        const int lds = words ? lds_w : S * S + S * G;
         if (lds > 64 * 1024)
             MM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(mm::preproc_gray_kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         mm::prof_before(4, (double)n * (3.0 * h->in_size * h->in_size + 4.0 * h->gray_size * h->gray_size), s, "preproc_gray");
+        if (words)
+            hipLaunchKernelGGL(mm::preproc_gray_words_kernel, dim3((unsigned)n), dim3(256), lds, s, frames, S, G, h->lan.ksize, h->d_lan_bounds,
+                               h->d_lan_kk, gray_out);
+        else
         hipLaunchKernelGGL(mm::preproc_gray_kernel, dim3((unsigned)n), dim3(256), lds, s, frames, h->in_size, h->gray_size,
                            h->lan.ksize, h->d_lan_bounds, h->d_lan_kk, gray_out);
         mm::prof_after(4, s);
@@ -402,6 +568,13 @@ int mm_preproc_forward(mm_preproc_t* h, const uint8_t* frames, int64_t n, float*
             return MM_ERR_UNSUPPORTED;   // (a down-scaling resize: not the reference's 112 -> 256)
         dim3 grid((unsigned)n, (unsigned)((h->crop + mm::RGB_ROWS - 1) / mm::RGB_ROWS));
         mm::prof_before(4, (double)n * (3.0 * h->in_size * h->in_size + 12.0 * (h->crop + 6) * (h->crop + 6)), s, "preproc_rgb3");
+        // word-wide LDS form when it applies (MM_PREPROC_WORDS=0: the byte form, for the A/B; read once)
+        static const bool rgb_words_on = !(getenv("MM_PREPROC_WORDS") && atoi(getenv("MM_PREPROC_WORDS")) == 0);
+        const int64_t lds_w = ((((int64_t)max_in * h->crop + 3) & ~3) + (int64_t)max_in * (h->in_size * 3 / 4) + 4) * 4;
+        if (rgb_words_on && h->crop <= 256 && (h->in_size * 3) % 4 == 0 && (reinterpret_cast<uintptr_t>(frames) & 3) == 0 && lds_w <= 56 * 1024)
+            hipLaunchKernelGGL(mm::preproc_rgb3_words_kernel, grid, dim3(256), (int)lds_w, s, frames, h->in_size, h->resize, h->crop,
+                               h->bil.ksize, h->d_bil_bounds, h->d_bil_kk, h->mean[0], h->mean[1], h->mean[2], rgb_out, max_in);
+        else
         hipLaunchKernelGGL(mm::preproc_rgb3_kernel, grid, dim3(256), (int)rgb3_lds, s, frames, h->in_size, h->resize, h->crop,
                            h->bil.ksize, h->d_bil_bounds, h->d_bil_kk, h->mean[0], h->mean[1], h->mean[2], rgb_out, max_in);
         mm::prof_after(4, s);
