@@ -84,3 +84,30 @@ def test_gpu_preprocessing_bit_exact_with_pil(pkg):
     assert (border == 0).all()
     with pytest.raises(RuntimeError):
         pp(torch.from_numpy(frames))
+
+
+@pytest.mark.gpu
+def test_gpu_preprocessing_word_and_byte_forms_agree(pkg):
+    """Round 6: preproc_gray_words_kernel / preproc_rgb3_words_kernel (every LDS access a word or wider: profiles/r06_ab_preproc_words.txt) need
+    4-byte aligned frames and fall back to the byte-wide kernels of rounds 2-5 otherwise.  The same frames at an aligned and at an odd
+    device address must give the same bits -- both equal to PIL -- so the launcher's choice changes no result."""
+    import torch
+    from mimamo_net_amd.preprocess import FramePreprocessor
+    dev = torch.device("cuda:0")
+    frames = np.concatenate([synthetic.make_clip_u8(5, 5), (weights.det_uniform("pp.noise2", (4, 112, 112, 3), 0, 256, 9)).astype(np.uint8)])
+    gray_ref, rgb_ref = synthetic.preprocess_host(frames)
+    pp = FramePreprocessor(device=dev)
+    aligned = torch.from_numpy(frames).to(dev)
+    raw = torch.empty(frames.size + 3, dtype=torch.uint8, device=dev)
+    outs = []
+    for shift in (0, 1, 2, 3):
+        view = raw[shift:shift + frames.size].view(frames.shape)
+        view.copy_(aligned)
+        assert view.data_ptr() % 4 == (raw.data_ptr() + shift) % 4
+        g, r3 = pp(view, bordered3=True)
+        outs.append((g.cpu().numpy(), r3.cpu().numpy()))
+    assert {(raw.data_ptr() + s) % 4 for s in range(4)} == {0, 1, 2, 3}         # one aligned view (word kernels), three odd ones (byte kernels)
+    for g, r3 in outs:
+        np.testing.assert_array_equal(g, gray_ref)
+        np.testing.assert_array_equal(r3[:, 3:227, 3:227, :].transpose(0, 3, 1, 2), rgb_ref)
+        np.testing.assert_array_equal(r3, outs[0][1])
