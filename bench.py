@@ -210,6 +210,20 @@ def sq_pass_summary(counter_csv, trace_csv, nsteps, conv_pats, phase_kernels):
     return clock, ({t: v / nsteps for t, v in valu.items()} if any(v > 0 for v in valu.values()) else None)
 
 
+def plausible_clock(clk):
+    """The live SQ pass derives the sustained clock as GRBM_GUI_ACTIVE / 8 XCDs / kernel-trace time.  The chip cannot run above its nominal
+    2.4 GHz and does not drop below ~1.5 GHz under this load: a value outside [1.2, 2.4 x 1.03] means the counter file and the kernel trace
+    of that profiler run disagree (seen once: 2.98 GHz, with the matrix-pipe busy fraction low by the same factor) -- the line then carries
+    no sustained-clock figures rather than wrong ones.  -> (clock dict or None, note or None)"""
+    if not clk:
+        return None, None
+    g = clk.get("GHz")
+    if g is None or not (1.2 <= g <= NOMINAL_CLOCK_GHZ * 1.03):
+        return None, ("live SQ / GRBM pass rejected: it implies %s GHz (nominal %.1f) -- GRBM_GUI_ACTIVE and the kernel trace of that profiler "
+                      "run disagree" % ("%.2f" % g if g is not None else "no", NOMINAL_CLOCK_GHZ))
+    return clk, None
+
+
 def phase_floors(live_rows, n_frames, valu_insts=None):
     """Per-kernel floors of the phase stage (round-5 verdict: the stage's floor is NOT the pyramid's MFMA floor alone -- the window kernels
     execute no MFMA and are VALU / LDS-issue bound).  live_rows: (cat, work, ms, tag) of one single-stream step from the library's
@@ -906,12 +920,12 @@ def run_rank(args):
     # (round 6) the 157.3 TFLOP/s denominator is the peak at the NOMINAL 2.4 GHz; under fp32-MFMA load the chip sustains 2.0-2.4 GHz.  `frac`
     # stays on the nominal peak; beside it the clock the conv launches actually ran at (GRBM_GUI_ACTIVE / kernel time, the live SQ pass) and
     # the fraction of the peak AT THAT CLOCK, so that "0.89 at 2.36 GHz, 91 % busy" reads as done and "0.60 at 2.17 GHz, 61 % busy" as open
-    clk = live_traffic.get("clock") if live_traffic else None
+    clk, clk_rejected = plausible_clock(live_traffic.get("clock") if live_traffic else None)
     result["roofline"]["sustained_clock_GHz"] = clk["GHz"] if clk else None
     result["roofline"]["mfma_busy_frac"] = clk["mfma_busy"] if clk else None
     result["roofline"]["peak_at_sustained_clock"] = PEAK_FP32_MFMA_TFLOPS * clk["GHz"] / NOMINAL_CLOCK_GHZ if clk else None
     result["roofline"]["frac_at_sustained_clock"] = conv_tflops / (PEAK_FP32_MFMA_TFLOPS * clk["GHz"] / NOMINAL_CLOCK_GHZ) if clk else None
-    result["roofline"]["clock_note"] = (clk["how"] if clk else
+    result["roofline"]["clock_note"] = (clk["how"] if clk else clk_rejected if clk_rejected else
                                         "no live SQ / GRBM pass (%s)" % ((live_traffic or {}).get("sq_pass_error") or (live_traffic or {}).get("error")
                                                                          or "not requested: --no-extra / --no-live-traffic / N > 1"))
     # both floors of the phase stage: HBM (algorithmic bytes at 8 TB/s) and the matrix pipes (the pyramid products: 4 344

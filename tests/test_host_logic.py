@@ -439,6 +439,18 @@ def test_sq_pass_summary_and_phase_floors(tmp_path):
     assert "floor_valu_ms" not in kern2["phase_window2<48>"] and kern2["phase_window2<48>"]["limiter"] == "hbm" and total2 < total
 
 
+def test_implausible_sustained_clock_is_dropped_not_reported():
+    """A live profiler pass whose GRBM_GUI_ACTIVE and kernel trace disagree (seen on one box in round 6: 2.98 GHz on a 2.4 GHz part, the
+    matrix-pipe busy fraction low by the same factor) must not put a `frac_at_sustained_clock` on the line."""
+    bench = _bench()
+    ok = {"GHz": 2.31, "mfma_busy": 0.77, "how": "x"}
+    assert bench.plausible_clock(ok) == (ok, None)
+    assert bench.plausible_clock(None) == (None, None)
+    for bad in (2.975, 0.4, None):
+        clk, note = bench.plausible_clock({"GHz": bad, "mfma_busy": 0.6, "how": "x"})
+        assert clk is None and "rejected" in note
+
+
 def test_every_profile_file_the_docs_quote_exists():
     """DESIGN.md / README.md / INTEGRATION.md and the profiles / tools indexes back their numbers with files under profiles/ (same-box A/B
     logs, rocprof summaries): a renamed or dropped log must not leave a dangling citation behind."""
