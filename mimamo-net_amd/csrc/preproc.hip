@@ -370,9 +370,11 @@ preproc_rgb3_words_kernel(const uint8_t* __restrict__ frames, int S, int R, int 
                 c2 += (int)((v >> 16) & 255u) * k;
             }
             float* dst = img + ((int64_t)(row0 + ry + 3) * CP + 3 + cx) * 3;
-            dst[0] = s_lut[0][clip8(c0)];
-            dst[1] = s_lut[1][clip8(c1)];
-            dst[2] = s_lut[2][clip8(c2)];
+            // streaming stores: 1.33 GB that the stem reads once, from HBM -- keeping it out of L2 is worth 15 % of this write-bound kernel
+            // (0.362 -> 0.306 ms, profiles/r06_ab_preproc_words.txt; the same hint on the window kernels' outputs measured slower)
+            __builtin_nontemporal_store(s_lut[0][clip8(c0)], dst);
+            __builtin_nontemporal_store(s_lut[1][clip8(c1)], dst + 1);
+            __builtin_nontemporal_store(s_lut[2][clip8(c2)], dst + 2);
         }
     }
 }
@@ -554,8 +556,8 @@ int mm_preproc_forward(mm_preproc_t* h, const uint8_t* frames, int64_t n, float*
             hipLaunchKernelGGL(mm::preproc_gray_words_kernel, dim3((unsigned)n), dim3(256), lds, s, frames, S, G, h->lan.ksize, h->d_lan_bounds,
                                h->d_lan_kk, gray_out);
         else
-        hipLaunchKernelGGL(mm::preproc_gray_kernel, dim3((unsigned)n), dim3(256), lds, s, frames, h->in_size, h->gray_size,
-                           h->lan.ksize, h->d_lan_bounds, h->d_lan_kk, gray_out);
+            hipLaunchKernelGGL(mm::preproc_gray_kernel, dim3((unsigned)n), dim3(256), lds, s, frames, h->in_size, h->gray_size,
+                               h->lan.ksize, h->d_lan_bounds, h->d_lan_kk, gray_out);
         mm::prof_after(4, s);
         MM_LAUNCH_CHECK();
     }
@@ -575,8 +577,8 @@ int mm_preproc_forward(mm_preproc_t* h, const uint8_t* frames, int64_t n, float*
             hipLaunchKernelGGL(mm::preproc_rgb3_words_kernel, grid, dim3(256), (int)lds_w, s, frames, h->in_size, h->resize, h->crop,
                                h->bil.ksize, h->d_bil_bounds, h->d_bil_kk, h->mean[0], h->mean[1], h->mean[2], rgb_out, max_in);
         else
-        hipLaunchKernelGGL(mm::preproc_rgb3_kernel, grid, dim3(256), (int)rgb3_lds, s, frames, h->in_size, h->resize, h->crop,
-                           h->bil.ksize, h->d_bil_bounds, h->d_bil_kk, h->mean[0], h->mean[1], h->mean[2], rgb_out, max_in);
+            hipLaunchKernelGGL(mm::preproc_rgb3_kernel, grid, dim3(256), (int)rgb3_lds, s, frames, h->in_size, h->resize, h->crop,
+                               h->bil.ksize, h->d_bil_bounds, h->d_bil_kk, h->mean[0], h->mean[1], h->mean[2], rgb_out, max_in);
         mm::prof_after(4, s);
         MM_LAUNCH_CHECK();
     } else if (rgb_out) {
